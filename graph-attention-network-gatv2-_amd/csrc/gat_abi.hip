@@ -1,0 +1,732 @@
+// gat_abi.hip — implementation of include/gatv2_abi.h: the context (device memory plan, stream,
+// event timing) and the C entry points that sequence the kernels of gat_edge_kernels.hip and
+// gat_dense_kernels.hip.  Replaces the inline allocation + launch code of the reference's main()
+// (GATv2_edge_based.cu E:1151-1357 memory plan, E:1370-1642 epoch loop).
+#include "gat_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace gat {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code ? code : GAT_E_INVALID;
+}
+
+struct Layer {
+    int32_t H = 0, D = 0, F = 0, HD = 0;
+    int64_t w_off = 0, a_off = 0;
+    float* PL = nullptr;      // [n_table][HD]  (table; may be caller-owned)
+    bool PL_bound = false;
+    float* PR = nullptr;      // [n_rows][HD]
+    float* alpha = nullptr;   // [E][H]
+    float* hpre = nullptr;    // [n_rows][HD]
+    float* hout = nullptr;    // [n_rows][HD] / last: [n_rows][D]
+    float* g = nullptr;       // [n_rows][HD]   dL/dh_pre (input_gradients[l], E:1339)
+    float* ge = nullptr;      // [E][H]  (keep_taps)
+    float* mstat = nullptr;   // [n_rows][H] (keep_taps)
+    float* zstat = nullptr;
+};
+
+struct Pending { int k; hipEvent_t e0, e1; };
+
+}  // namespace gat
+
+struct gat_ctx {
+    gat_config cfg{};
+    std::vector<int32_t> heads, outdims;
+    std::vector<gat::Layer> layers;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n_rows = 0, n_edges = 0, n_table = 0, table_row0 = 0;
+    bool have_graph = false, have_x = false, have_labels = false, buffers_ready = false;
+    int32_t* row_ptr = nullptr; int32_t* col_idx = nullptr; int32_t* labels = nullptr;
+    float* X0 = nullptr;
+    int64_t nW = 0, nA = 0, nWo = 0;
+    float* params = nullptr;   // [W | a | Wo]
+    float* grads = nullptr;    // [gradW | grada | gradWo]
+    float* adam_m = nullptr; float* adam_v = nullptr;
+    int32_t HDmax = 0, Hmax = 0;
+    float* gPL = nullptr; bool gPL_bound = false;   // [n_table][HDmax]
+    float* gPR = nullptr;                           // [n_rows][HDmax]
+    float* ga_partial = nullptr; int32_t ga_blocks = 0;
+    float* gw_scratch = nullptr;
+    float* hb_partial = nullptr;
+    double* loss_partial = nullptr; int32_t* correct_partial = nullptr;
+    float* loss_out = nullptr; int32_t* correct_out = nullptr;
+    float* clip_scratch = nullptr;
+    float* y = nullptr;
+    // timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+    std::vector<gat::Pending> ev_pending;
+    int64_t k_launches[GAT_K_COUNT] = {0};
+    double k_ms[GAT_K_COUNT] = {0};
+    std::vector<void*> owned;   // every hipMalloc of this context
+};
+
+namespace gat {
+
+static int dmalloc(gat_ctx* c, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 4;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(GAT_E_NOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    }
+    c->owned.push_back(*p);
+    return 0;
+}
+template <class T>
+static int dalloc(gat_ctx* c, T** p, int64_t count) { return dmalloc(c, (void**)p, (size_t)count * sizeof(T)); }
+
+static void dfree(gat_ctx* c, void* p) {
+    if (!p) return;
+    auto it = std::find(c->owned.begin(), c->owned.end(), p);
+    if (it != c->owned.end()) { c->owned.erase(it); (void)hipFree(p); }
+}
+
+// ---- event timing ------------------------------------------------------------------------------
+static int flush_events(gat_ctx* c) {
+    if (c->ev_pending.empty()) return 0;
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    for (auto& p : c->ev_pending) {
+        float ms = 0.f;
+        GAT_HIP(hipEventElapsedTime(&ms, p.e0, p.e1));
+        c->k_ms[p.k] += ms;
+        c->k_launches[p.k] += 1;
+        c->ev_free.emplace_back(p.e0, p.e1);
+    }
+    c->ev_pending.clear();
+    return 0;
+}
+struct Scope {      // brackets the launches of one kernel class with a HIP event pair
+    gat_ctx* c; int k; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
+    Scope(gat_ctx* c_, int k_) : c(c_), k(k_), on(c_->cfg.collect_timing != 0) {
+        if (!on) return;
+        if (c->ev_pending.size() >= 2048) (void)flush_events(c);
+        if (c->ev_free.empty()) {
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+        } else { e0 = c->ev_free.back().first; e1 = c->ev_free.back().second; c->ev_free.pop_back(); }
+        (void)hipEventRecord(e0, c->stream);
+    }
+    ~Scope() {
+        if (!on) return;
+        (void)hipEventRecord(e1, c->stream);
+        c->ev_pending.push_back({k, e0, e1});
+    }
+};
+
+static int check_layer(gat_ctx* c, int32_t l) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    if (l < 0 || l >= c->cfg.num_layers) return fail(GAT_E_INVALID, "layer index out of range");
+    if (!c->buffers_ready) return fail(GAT_E_STATE, "set_graph / set_features / set_labels must come first");
+    return 0;
+}
+
+static float* W_of(gat_ctx* c, int l) { return c->params + c->layers[l].w_off; }
+static float* a_of(gat_ctx* c, int l) { return c->params + c->nW + c->layers[l].a_off; }
+static float* Wo_of(gat_ctx* c) { return c->params + c->nW + c->nA; }
+static float* gW_of(gat_ctx* c, int l) { return c->grads + c->layers[l].w_off; }
+static float* ga_of(gat_ctx* c, int l) { return c->grads + c->nW + c->layers[l].a_off; }
+static float* gWo_of(gat_ctx* c) { return c->grads + c->nW + c->nA; }
+static const float* Xin_of(gat_ctx* c, int l) { return l == 0 ? c->X0 : c->layers[l - 1].hout; }
+
+// (re)allocate everything that depends on the graph size
+static int ensure_buffers(gat_ctx* c) {
+    if (c->buffers_ready) return 0;
+    if (!(c->have_graph && c->have_x && c->have_labels)) return 0;
+    const int L = c->cfg.num_layers;
+    const int64_t N = c->n_rows, E = c->n_edges, T = c->n_table;
+    for (int l = 0; l < L; ++l) {
+        Layer& y = c->layers[l];
+        if (!y.PL_bound) GAT_TRY(dalloc(c, &y.PL, T * y.HD));
+        GAT_TRY(dalloc(c, &y.PR, N * y.HD));
+        GAT_TRY(dalloc(c, &y.alpha, E * y.H));
+        GAT_TRY(dalloc(c, &y.hpre, N * y.HD));
+        GAT_TRY(dalloc(c, &y.hout, N * (l == L - 1 ? y.D : y.HD)));
+        GAT_TRY(dalloc(c, &y.g, N * y.HD));
+        if (c->cfg.keep_taps) {
+            GAT_TRY(dalloc(c, &y.ge, E * y.H));
+            GAT_TRY(dalloc(c, &y.mstat, N * y.H));
+            GAT_TRY(dalloc(c, &y.zstat, N * y.H));
+        }
+    }
+    if (!c->gPL_bound) GAT_TRY(dalloc(c, &c->gPL, T * c->HDmax));
+    GAT_TRY(dalloc(c, &c->gPR, N * c->HDmax));
+    c->ga_blocks = edge_backward_blocks(N);
+    GAT_TRY(dalloc(c, &c->ga_partial, (int64_t)c->ga_blocks * c->HDmax));
+    int64_t gw = 1;
+    for (int l = 0; l < L; ++l) gw = std::max(gw, grad_w_scratch_floats(N, c->layers[l].F, c->layers[l].HD));
+    GAT_TRY(dalloc(c, &c->gw_scratch, gw));
+    const int C = c->cfg.num_classes, DL = c->layers[L - 1].D;
+    GAT_TRY(dalloc(c, &c->hb_partial, (int64_t)head_bwd_blocks(N, C, DL) * C * DL));
+    GAT_TRY(dalloc(c, &c->loss_partial, head_blocks(N)));
+    GAT_TRY(dalloc(c, &c->correct_partial, head_blocks(N)));
+    GAT_TRY(dalloc(c, &c->loss_out, 1));
+    GAT_TRY(dalloc(c, &c->correct_out, 1));
+    GAT_TRY(dalloc(c, &c->y, N * C));
+    c->buffers_ready = true;
+    return 0;
+}
+
+static uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static float uniform01_open_closed(uint64_t& s) {      // (0, 1] like curand_uniform (E:217)
+    return ((float)(splitmix64(s) >> 40) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+}  // namespace gat
+
+using namespace gat;
+
+extern "C" {
+
+const char* gat_last_error(void) { return g_err.c_str(); }
+int gat_abi_version(void) { return GAT_ABI_VERSION; }
+int gat_device_count(int* count) {
+    if (!count) return fail(GAT_E_INVALID, "null count");
+    GAT_HIP(hipGetDeviceCount(count));
+    return 0;
+}
+int gat_mem_info(size_t* free_bytes, size_t* total_bytes) {
+    GAT_HIP(hipMemGetInfo(free_bytes, total_bytes));
+    return 0;
+}
+
+int gat_create(const gat_config* cfg, gat_ctx** out) {
+    if (!cfg || !out) return fail(GAT_E_INVALID, "gat_create: null argument");
+    if (cfg->num_layers <= 0) return fail(GAT_E_INVALID, "Number of layers must be > 0");
+    if (!cfg->heads || !cfg->outdims) return fail(GAT_E_INVALID, "--heads and --outdims are required (no defaults, E:954-955)");
+    if (cfg->in_dim <= 0 || cfg->num_classes <= 0) return fail(GAT_E_INVALID, "in_dim and num_classes must be > 0");
+    GAT_HIP(hipSetDevice(cfg->device));
+    std::unique_ptr<gat_ctx> c(new gat_ctx());
+    c->cfg = *cfg;
+    c->heads.assign(cfg->heads, cfg->heads + cfg->num_layers);
+    c->outdims.assign(cfg->outdims, cfg->outdims + cfg->num_layers);
+    c->cfg.heads = c->heads.data();
+    c->cfg.outdims = c->outdims.data();
+    if (c->cfg.negative_slope == 0.0f) c->cfg.negative_slope = 0.01f;
+    c->layers.resize(cfg->num_layers);
+    int64_t woff = 0, aoff = 0;
+    for (int l = 0; l < cfg->num_layers; ++l) {
+        Layer& y = c->layers[l];
+        y.H = c->heads[l]; y.D = c->outdims[l];
+        if (y.H <= 0 || y.D <= 0) return fail(GAT_E_INVALID, "heads/outdims must be positive");
+        y.HD = y.H * y.D;
+        y.F = (l == 0) ? cfg->in_dim : c->layers[l - 1].HD;            // E:1115-1118
+        y.w_off = woff; y.a_off = aoff;
+        woff += (int64_t)y.HD * 2 * y.F;                                 // E:1248-1254
+        aoff += y.HD;
+        c->HDmax = std::max(c->HDmax, y.HD);
+        c->Hmax = std::max(c->Hmax, y.H);
+    }
+    c->nW = woff; c->nA = aoff;
+    c->nWo = (int64_t)cfg->num_classes * c->layers.back().D;
+    if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
+    else { GAT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    gat_ctx* p = c.get();
+    const int64_t np = c->nW + c->nA + c->nWo;
+    GAT_TRY(dalloc(p, &p->params, np));
+    GAT_TRY(dalloc(p, &p->grads, np));
+    GAT_TRY(dalloc(p, &p->clip_scratch, 4));
+    GAT_HIP(hipMemsetAsync(p->params, 0, np * sizeof(float), p->stream));
+    GAT_HIP(hipMemsetAsync(p->grads, 0, np * sizeof(float), p->stream));
+    *out = c.release();
+    return 0;
+}
+
+int gat_destroy(gat_ctx* c) {
+    if (!c) return 0;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->ev_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    for (auto& p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (void* p : c->owned) (void)hipFree(p);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int gat_sync(gat_ctx* c) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- data -------------------------------------------------------------------------------------------------
+static int set_graph_common(gat_ctx* c, const int32_t* row_ptr, const int32_t* col_idx, int64_t n_rows,
+                            int64_t n_edges, int64_t n_table, int64_t table_row0, hipMemcpyKind kind) {
+    if (!c || !row_ptr || (!col_idx && n_edges > 0)) return fail(GAT_E_INVALID, "gat_set_graph: null argument");
+    if (c->have_graph) return fail(GAT_E_STATE, "gat_set_graph: graph already set (create a new context)");
+    if (n_rows <= 0 || n_edges < 0) return fail(GAT_E_INVALID, "gat_set_graph: bad sizes");
+    if (n_edges > 0x7fffffffLL || n_rows >= 0x7fffffffLL || n_table > 0x7fffffffLL)
+        return fail(GAT_E_UNSUPPORTED, "gat_set_graph: int32 CSR limits (E:1045-1046) exceeded");
+    if (table_row0 < 0 || table_row0 + n_rows > n_table) return fail(GAT_E_INVALID, "gat_set_graph: shard rows outside the table");
+    if (kind == hipMemcpyHostToDevice) {
+        if (row_ptr[0] != 0 || (int64_t)row_ptr[n_rows] != n_edges)
+            return fail(GAT_E_INVALID, "Invalid row_ptr: must start at 0 and end at the edge count");
+        for (int64_t i = 0; i < n_rows; ++i)
+            if (row_ptr[i + 1] < row_ptr[i]) return fail(GAT_E_INVALID, "Invalid row_ptr: not monotone");
+        for (int64_t e = 0; e < n_edges; ++e)
+            if (col_idx[e] < 0 || (int64_t)col_idx[e] >= n_table) return fail(GAT_E_INVALID, "col_idx entry outside the node table");
+    }
+    c->n_rows = n_rows; c->n_edges = n_edges; c->n_table = n_table; c->table_row0 = table_row0;
+    GAT_TRY(dalloc(c, &c->row_ptr, n_rows + 1));
+    GAT_TRY(dalloc(c, &c->col_idx, n_edges));
+    GAT_HIP(hipMemcpyAsync(c->row_ptr, row_ptr, (n_rows + 1) * sizeof(int32_t), kind, c->stream));
+    if (n_edges > 0) GAT_HIP(hipMemcpyAsync(c->col_idx, col_idx, n_edges * sizeof(int32_t), kind, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    c->have_graph = true;
+    return ensure_buffers(c);
+}
+int gat_set_graph(gat_ctx* c, const int32_t* row_ptr, const int32_t* col_idx, int64_t n_rows, int64_t n_edges,
+                  int64_t n_table, int64_t table_row0) {
+    return set_graph_common(c, row_ptr, col_idx, n_rows, n_edges, n_table, table_row0, hipMemcpyHostToDevice);
+}
+int gat_set_graph_device(gat_ctx* c, const int32_t* row_ptr, const int32_t* col_idx, int64_t n_rows,
+                         int64_t n_edges, int64_t n_table, int64_t table_row0) {
+    return set_graph_common(c, row_ptr, col_idx, n_rows, n_edges, n_table, table_row0, hipMemcpyDeviceToDevice);
+}
+
+static int set_features_common(gat_ctx* c, const float* x, int64_t n_rows, int32_t in_dim, hipMemcpyKind kind) {
+    if (!c || !x) return fail(GAT_E_INVALID, "gat_set_features: null argument");
+    if (in_dim != c->cfg.in_dim) return fail(GAT_E_INVALID, "gat_set_features: in_dim differs from the config");
+    if (c->have_graph && n_rows != c->n_rows) return fail(GAT_E_INVALID, "gat_set_features: row count differs from the graph");
+    if (!c->X0) GAT_TRY(dalloc(c, &c->X0, n_rows * in_dim));
+    GAT_HIP(hipMemcpyAsync(c->X0, x, (size_t)n_rows * in_dim * sizeof(float), kind, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    c->have_x = true;
+    return ensure_buffers(c);
+}
+int gat_set_features(gat_ctx* c, const float* x, int64_t n_rows, int32_t in_dim) {
+    return set_features_common(c, x, n_rows, in_dim, hipMemcpyHostToDevice);
+}
+int gat_set_features_device(gat_ctx* c, const float* x, int64_t n_rows, int32_t in_dim) {
+    return set_features_common(c, x, n_rows, in_dim, hipMemcpyDeviceToDevice);
+}
+static int set_labels_common(gat_ctx* c, const int32_t* labels, int64_t n_rows, hipMemcpyKind kind) {
+    if (!c || !labels) return fail(GAT_E_INVALID, "gat_set_labels: null argument");
+    if (c->have_graph && n_rows != c->n_rows) return fail(GAT_E_INVALID, "Invalid labels length");
+    if (kind == hipMemcpyHostToDevice)
+        for (int64_t i = 0; i < n_rows; ++i)
+            if (labels[i] < 0 || labels[i] >= c->cfg.num_classes) return fail(GAT_E_INVALID, "label outside [0, num_classes)");
+    if (!c->labels) GAT_TRY(dalloc(c, &c->labels, n_rows));
+    GAT_HIP(hipMemcpyAsync(c->labels, labels, n_rows * sizeof(int32_t), kind, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    c->have_labels = true;
+    return ensure_buffers(c);
+}
+int gat_set_labels(gat_ctx* c, const int32_t* labels, int64_t n_rows) {
+    return set_labels_common(c, labels, n_rows, hipMemcpyHostToDevice);
+}
+int gat_set_labels_device(gat_ctx* c, const int32_t* labels, int64_t n_rows) {
+    return set_labels_common(c, labels, n_rows, hipMemcpyDeviceToDevice);
+}
+
+// ---- parameters --------------------------------------------------------------------------------------------
+static int group_span(gat_ctx* c, int group, int64_t* off, int64_t* cnt) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    switch (group) {
+        case GAT_PARAM_W: *off = 0; *cnt = c->nW; return 0;
+        case GAT_PARAM_A: *off = c->nW; *cnt = c->nA; return 0;
+        case GAT_PARAM_WO: *off = c->nW + c->nA; *cnt = c->nWo; return 0;
+        default: return fail(GAT_E_INVALID, "unknown parameter group");
+    }
+}
+int gat_param_count(gat_ctx* c, int group, int64_t* count) {
+    int64_t off;
+    return group_span(c, group, &off, count);
+}
+static int copy_group(gat_ctx* c, float* base, int group, float* host, int64_t count, bool to_device) {
+    int64_t off, cnt;
+    GAT_TRY(group_span(c, group, &off, &cnt));
+    if (count != cnt || !host) return fail(GAT_E_INVALID, "parameter group size mismatch");
+    if (to_device) GAT_HIP(hipMemcpyAsync(base + off, host, cnt * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    else GAT_HIP(hipMemcpyAsync(host, base + off, cnt * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int gat_params_set(gat_ctx* c, int group, const float* host, int64_t count) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    return copy_group(c, c->params, group, const_cast<float*>(host), count, true);
+}
+int gat_params_get(gat_ctx* c, int group, float* host, int64_t count) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    return copy_group(c, c->params, group, host, count, false);
+}
+int gat_grads_get(gat_ctx* c, int group, float* host, int64_t count) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    return copy_group(c, c->grads, group, host, count, false);
+}
+int gat_grads_set(gat_ctx* c, int group, const float* host, int64_t count) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    return copy_group(c, c->grads, group, const_cast<float*>(host), count, true);
+}
+int gat_grads_device(gat_ctx* c, void** d_ptr, int64_t* count) {
+    if (!c || !d_ptr || !count) return fail(GAT_E_INVALID, "null argument");
+    *d_ptr = c->grads; *count = c->nW + c->nA + c->nWo;
+    return 0;
+}
+
+int gat_params_init(gat_ctx* c, uint64_t seed) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    // Same distribution as xavier_init_kernel_curand (E:205-242); own counter-based stream, since
+    // the reference's cuRAND XORWOW stream is seeded with time(NULL) (E:1305) and unreproducible.
+    std::vector<float> h(c->nW + c->nA + c->nWo);
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x67617432ull;
+    for (int l = 0; l < c->cfg.num_layers; ++l) {
+        const Layer& y = c->layers[l];
+        const float lim = sqrtf(6.0f / (float)(2 * y.F + y.D));
+        float* w = h.data() + y.w_off;
+        for (int64_t i = 0; i < (int64_t)y.HD * 2 * y.F; ++i) w[i] = uniform01_open_closed(s) * 2.0f * lim - lim;
+        float* a = h.data() + c->nW + y.a_off;
+        for (int i = 0; i < y.HD; ++i) a[i] = uniform01_open_closed(s) * 2.0f * lim - lim;
+    }
+    const int DL = c->layers.back().D;
+    const float limo = sqrtf(6.0f / (float)(c->cfg.num_classes + DL));
+    float* wo = h.data() + c->nW + c->nA;
+    for (int64_t i = 0; i < c->nWo; ++i) wo[i] = uniform01_open_closed(s) * 2.0f * limo - limo;
+    GAT_HIP(hipMemcpyAsync(c->params, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- phases --------------------------------------------------------------------------------------------------
+int gat_layer_project(gat_ctx* c, int32_t l) {
+    GAT_TRY(check_layer(c, l));
+    Layer& y = c->layers[l];
+    Scope t(c, GAT_K_PROJECT);
+    return launch_project(Xin_of(c, l), W_of(c, l), y.PL + c->table_row0 * y.HD, y.PR, c->n_rows, y.F, y.HD, c->stream);
+}
+
+int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
+    GAT_TRY(check_layer(c, l));
+    Layer& y = c->layers[l];
+    EdgeFwdArgs a{};
+    a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
+    a.alpha = y.alpha; a.hpre = y.hpre; a.hout = y.hout; a.mstat = y.mstat; a.zstat = y.zstat;
+    a.n_rows = c->n_rows; a.H = y.H; a.D = y.D; a.is_last = (l == c->cfg.num_layers - 1);
+    a.slope = c->cfg.negative_slope;
+    Scope t(c, GAT_K_EDGE_FWD);
+    return launch_edge_forward(a, c->stream);
+}
+
+int gat_head_forward(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
+    GAT_TRY(check_layer(c, 0));
+    const Layer& y = c->layers.back();
+    HeadArgs a{};
+    a.Wo = Wo_of(c); a.HL = y.hout; a.labels = c->labels; a.y = c->y;
+    a.loss_partial = c->loss_partial; a.correct_partial = c->correct_partial;
+    a.loss_out = c->loss_out; a.correct_out = c->correct_out;
+    a.n_rows = c->n_rows; a.C = c->cfg.num_classes; a.DL = y.D;
+    {
+        Scope t(c, GAT_K_HEAD_FWD);
+        GAT_TRY(launch_head_forward(a, c->stream));
+    }
+    if (loss_sum || n_correct) {
+        float hl = 0.f; int32_t hc = 0;
+        GAT_HIP(hipMemcpyAsync(&hl, c->loss_out, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        GAT_HIP(hipMemcpyAsync(&hc, c->correct_out, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        GAT_HIP(hipStreamSynchronize(c->stream));
+        if (loss_sum) *loss_sum = hl;
+        if (n_correct) *n_correct = hc;
+    }
+    return 0;
+}
+
+int gat_head_backward(gat_ctx* c) {
+    GAT_TRY(check_layer(c, 0));
+    const Layer& y = c->layers.back();
+    HeadBwdArgs a{};
+    a.Wo = Wo_of(c); a.HL = y.hout; a.y = c->y; a.labels = c->labels; a.hpre = y.hpre; a.g = y.g;
+    a.gradWo = gWo_of(c); a.partial = c->hb_partial; a.n_rows = c->n_rows; a.C = c->cfg.num_classes;
+    a.DL = y.D; a.H = y.H; a.slope = c->cfg.negative_slope; a.flat_index = c->cfg.flat_lrelu_index;
+    Scope t(c, GAT_K_HEAD_BWD);
+    return launch_head_backward(a, c->stream);
+}
+
+int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
+    GAT_TRY(check_layer(c, l));
+    Layer& y = c->layers[l];
+    {
+        Scope t(c, GAT_K_MISC);
+        GAT_HIP(hipMemsetAsync(c->gPL, 0, (size_t)c->n_table * y.HD * sizeof(float), c->stream));
+    }
+    EdgeBwdArgs a{};
+    a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
+    a.alpha = y.alpha; a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge;
+    a.ga_partial = c->ga_partial; a.ga_blocks = c->ga_blocks; a.n_rows = c->n_rows; a.H = y.H; a.D = y.D;
+    a.slope = c->cfg.negative_slope;
+    {
+        Scope t(c, GAT_K_EDGE_BWD);
+        GAT_TRY(launch_edge_backward(a, c->stream));
+    }
+    Scope t(c, GAT_K_MISC);
+    return launch_reduce_partials_add(c->ga_partial, c->ga_blocks, y.HD, ga_of(c, l), c->stream);
+}
+
+int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
+    GAT_TRY(check_layer(c, l));
+    Layer& y = c->layers[l];
+    const float* gPL_rows = c->gPL + c->table_row0 * y.HD;
+    {
+        Scope t(c, GAT_K_GRAD_W);
+        GAT_TRY(launch_grad_w(gPL_rows, c->gPR, Xin_of(c, l), gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, c->stream));
+    }
+    if (l == 0) return 0;                                             // E:1528
+    Scope t(c, GAT_K_GRAD_X);
+    return launch_grad_x(gPL_rows, c->gPR, W_of(c, l), c->layers[l - 1].hpre, c->layers[l - 1].g, c->n_rows, y.F,
+                         y.HD, c->cfg.negative_slope, c->stream);
+}
+
+// ---- whole step (single shard) ---------------------------------------------------------------------------------
+int gat_forward(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
+    GAT_TRY(check_layer(c, 0));
+    if (c->n_table != c->n_rows)
+        return fail(GAT_E_STATE, "gat_forward: sharded context — drive the phase API with the exchange steps");
+    for (int l = 0; l < c->cfg.num_layers; ++l) {
+        GAT_TRY(gat_layer_project(c, l));
+        GAT_TRY(gat_layer_forward_edges(c, l));
+    }
+    return gat_head_forward(c, loss_sum, n_correct);
+}
+int gat_backward(gat_ctx* c) {
+    GAT_TRY(check_layer(c, 0));
+    if (c->n_table != c->n_rows)
+        return fail(GAT_E_STATE, "gat_backward: sharded context — drive the phase API with the exchange steps");
+    GAT_TRY(gat_head_backward(c));
+    for (int l = c->cfg.num_layers - 1; l >= 0; --l) {
+        GAT_TRY(gat_layer_backward_edges(c, l));
+        GAT_TRY(gat_layer_backward_dense(c, l));
+    }
+    return 0;
+}
+int gat_zero_grad(gat_ctx* c) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    Scope t(c, GAT_K_MISC);
+    GAT_HIP(hipMemsetAsync(c->grads, 0, (size_t)(c->nW + c->nA + c->nWo) * sizeof(float), c->stream));
+    return 0;
+}
+int gat_clip(gat_ctx* c, float threshold) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    Scope t(c, GAT_K_MISC);
+    GAT_TRY(launch_clip(c->grads, c->nW, threshold, c->clip_scratch, c->stream));
+    GAT_TRY(launch_clip(c->grads + c->nW, c->nA, threshold, c->clip_scratch + 1, c->stream));
+    return launch_clip(c->grads + c->nW + c->nA, c->nWo, threshold, c->clip_scratch + 2, c->stream);
+}
+int gat_step_sgd(gat_ctx* c, float lr) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    Scope t(c, GAT_K_MISC);
+    return launch_sgd(c->params, c->grads, lr, c->nW + c->nA + c->nWo, c->stream);
+}
+int gat_step_adam(gat_ctx* c, float lr, float b1, float b2, float eps, int32_t t_) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    if (!(b1 > 0.f && b1 < 1.f && b2 > 0.f && b2 < 1.f))
+        return fail(GAT_E_INVALID, "For Adam optimizer, beta1 and beta2 must be in (0,1).");
+    const int64_t np = c->nW + c->nA + c->nWo;
+    if (!c->adam_m) {
+        GAT_TRY(dalloc(c, &c->adam_m, np));
+        GAT_TRY(dalloc(c, &c->adam_v, np));
+        GAT_HIP(hipMemsetAsync(c->adam_m, 0, np * sizeof(float), c->stream));
+        GAT_HIP(hipMemsetAsync(c->adam_v, 0, np * sizeof(float), c->stream));
+    }
+    Scope t(c, GAT_K_MISC);
+    return launch_adam(c->params, c->grads, c->adam_m, c->adam_v, lr, np, b1, b2, eps, t_, c->stream);
+}
+
+// ---- exchange tables ----------------------------------------------------------------------------------------------
+int gat_table(gat_ctx* c, int which, int32_t l, void** d_ptr, int64_t* n_rows, int64_t* row_floats) {
+    GAT_TRY(check_layer(c, l));
+    if (!d_ptr) return fail(GAT_E_INVALID, "null argument");
+    if (which == GAT_TABLE_PL) *d_ptr = c->layers[l].PL;
+    else if (which == GAT_TABLE_GPL) *d_ptr = c->gPL;
+    else return fail(GAT_E_INVALID, "unknown table");
+    if (n_rows) *n_rows = c->n_table;
+    if (row_floats) *row_floats = c->layers[l].HD;
+    return 0;
+}
+int gat_bind_table(gat_ctx* c, int which, int32_t l, void* d_ptr, int64_t bytes) {
+    if (!c || !d_ptr) return fail(GAT_E_INVALID, "null argument");
+    if (l < 0 || l >= c->cfg.num_layers) return fail(GAT_E_INVALID, "layer index out of range");
+    if (!c->have_graph) return fail(GAT_E_STATE, "gat_bind_table: set the graph first");
+    if (which == GAT_TABLE_PL) {
+        Layer& y = c->layers[l];
+        if (bytes < (int64_t)c->n_table * y.HD * (int64_t)sizeof(float)) return fail(GAT_E_INVALID, "bound PL table too small");
+        if (!y.PL_bound) dfree(c, y.PL);
+        y.PL = (float*)d_ptr; y.PL_bound = true;
+        return 0;
+    }
+    if (which == GAT_TABLE_GPL) {
+        if (bytes < (int64_t)c->n_table * c->HDmax * (int64_t)sizeof(float)) return fail(GAT_E_INVALID, "bound gPL table too small (needs n_table*max(H*D) floats)");
+        if (!c->gPL_bound) dfree(c, c->gPL);
+        c->gPL = (float*)d_ptr; c->gPL_bound = true;
+        return 0;
+    }
+    return fail(GAT_E_INVALID, "unknown table");
+}
+
+// ---- taps ----------------------------------------------------------------------------------------------------------
+static int d2h(gat_ctx* c, void* host, const void* dev, size_t bytes) {
+    GAT_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int gat_tap(gat_ctx* c, int tensor, int32_t l, void* host, int64_t count) {
+    GAT_TRY(check_layer(c, l));
+    if (!host) return fail(GAT_E_INVALID, "null destination");
+    const Layer& y = c->layers[l];
+    const int64_t N = c->n_rows, E = c->n_edges;
+    const bool last = (l == c->cfg.num_layers - 1);
+    auto need = [&](int64_t n) { return n == count ? 0 : fail(GAT_E_INVALID, "gat_tap: count mismatch"); };
+    auto transposed = [&](const float* src, int64_t A_, int32_t B_, bool eh) -> int {
+        if (!src) return fail(GAT_E_STATE, "gat_tap: tensor not kept (create the context with keep_taps=1)");
+        float* tmp = nullptr;
+        GAT_HIP(hipMalloc((void**)&tmp, (size_t)std::max<int64_t>(A_ * B_, 1) * sizeof(float)));
+        int rc = eh ? launch_transpose_eh_to_he(src, tmp, A_, B_, c->stream) : launch_transpose_nh_to_hn(src, tmp, A_, B_, c->stream);
+        if (rc == 0) rc = d2h(c, host, tmp, (size_t)A_ * B_ * sizeof(float));
+        (void)hipFree(tmp);
+        return rc;
+    };
+    switch (tensor) {
+        case GAT_TAP_SRC: GAT_TRY(need(E)); return d2h(c, host, c->col_idx, E * sizeof(int32_t));
+        case GAT_TAP_DST: {
+            GAT_TRY(need(E));
+            int32_t *s = nullptr, *d = nullptr;
+            GAT_HIP(hipMalloc((void**)&s, std::max<int64_t>(E, 1) * sizeof(int32_t)));
+            GAT_HIP(hipMalloc((void**)&d, std::max<int64_t>(E, 1) * sizeof(int32_t)));
+            int rc = launch_csr_to_coo(c->row_ptr, c->col_idx, s, d, N, E, 0, c->stream);
+            if (rc == 0) rc = d2h(c, host, d, E * sizeof(int32_t));
+            (void)hipFree(s); (void)hipFree(d);
+            return rc;
+        }
+        case GAT_TAP_ALPHA: GAT_TRY(need(E * y.H)); return transposed(y.alpha, E, y.H, true);
+        case GAT_TAP_GE: GAT_TRY(need(E * y.H)); return transposed(y.ge, E, y.H, true);
+        case GAT_TAP_MAX: GAT_TRY(need(N * y.H)); return transposed(y.mstat, N, y.H, false);
+        case GAT_TAP_SUM: GAT_TRY(need(N * y.H)); return transposed(y.zstat, N, y.H, false);
+        case GAT_TAP_HPRE: GAT_TRY(need(N * y.HD)); return d2h(c, host, y.hpre, N * y.HD * sizeof(float));
+        case GAT_TAP_HOUT: { const int64_t n = N * (last ? y.D : y.HD); GAT_TRY(need(n)); return d2h(c, host, y.hout, n * sizeof(float)); }
+        case GAT_TAP_Y: GAT_TRY(need(N * c->cfg.num_classes)); return d2h(c, host, c->y, N * c->cfg.num_classes * sizeof(float));
+        case GAT_TAP_G: GAT_TRY(need(N * y.HD)); return d2h(c, host, y.g, N * y.HD * sizeof(float));
+        case GAT_TAP_PL: GAT_TRY(need(c->n_table * y.HD)); return d2h(c, host, y.PL, c->n_table * y.HD * sizeof(float));
+        case GAT_TAP_PR: GAT_TRY(need(N * y.HD)); return d2h(c, host, y.PR, N * y.HD * sizeof(float));
+        default: return fail(GAT_E_INVALID, "gat_tap: unknown tensor id");
+    }
+}
+
+// ---- op-level entry points ------------------------------------------------------------------------------------------
+int gat_op_csr_to_coo(const int32_t* d_row_ptr, const int32_t* d_col_idx, int32_t* d_src, int32_t* d_dst,
+                      int64_t n_rows, int64_t n_edges, void* stream) {
+    if (!d_row_ptr || !d_src || !d_dst || (!d_col_idx && n_edges > 0)) return fail(GAT_E_INVALID, "null argument");
+    return launch_csr_to_coo(d_row_ptr, d_col_idx, d_src, d_dst, n_rows, n_edges, 0, (hipStream_t)stream);
+}
+
+struct TmpBufs {
+    std::vector<void*> p;
+    ~TmpBufs() { for (void* q : p) (void)hipFree(q); }
+    int get(float** out, int64_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, (size_t)std::max<int64_t>(n, 1) * sizeof(float));
+        if (e != hipSuccess) return fail(GAT_E_NOMEM, hipGetErrorString(e));
+        p.push_back(q); *out = (float*)q;
+        return 0;
+    }
+};
+
+int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, const float* d_x, const float* d_w,
+                         const float* d_a, float* d_attn_coeff, float* d_hpre, float* d_hout, int64_t n, int64_t e,
+                         int32_t f, int32_t h, int32_t d, int32_t is_last, float slope, void* stream) {
+    if (!d_row_ptr || !d_x || !d_w || !d_a || !d_attn_coeff || !d_hpre || !d_hout) return fail(GAT_E_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int HD = h * d;
+    TmpBufs t;
+    float *PL, *PR, *alpha;
+    GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, s));
+    EdgeFwdArgs a{};
+    a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
+    a.hpre = d_hpre; a.hout = d_hout; a.n_rows = n; a.H = h; a.D = d; a.is_last = is_last; a.slope = slope;
+    GAT_TRY(launch_edge_forward(a, s));
+    GAT_TRY(launch_transpose_eh_to_he(alpha, d_attn_coeff, e, h, s));
+    GAT_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, const float* d_x, const float* d_w,
+                          const float* d_a, const float* d_attn_coeff, const float* d_hpre, const float* d_g,
+                          float* d_grad_w, float* d_grad_a, const float* d_hpre_prev, float* d_g_prev, int64_t n,
+                          int64_t e, int32_t f, int32_t h, int32_t d, float slope, void* stream) {
+    if (!d_row_ptr || !d_x || !d_w || !d_a || !d_attn_coeff || !d_hpre || !d_g || !d_grad_w || !d_grad_a)
+        return fail(GAT_E_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int HD = h * d;
+    TmpBufs t;
+    float *PL, *PR, *alpha, *gPL, *gPR, *gap, *scr;
+    const int blocks = edge_backward_blocks(n);
+    GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
+    GAT_TRY(t.get(&gPL, n * HD)); GAT_TRY(t.get(&gPR, n * HD)); GAT_TRY(t.get(&gap, (int64_t)blocks * HD));
+    GAT_TRY(t.get(&scr, grad_w_scratch_floats(n, f, HD)));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, s));
+    GAT_TRY(launch_transpose_he_to_eh(d_attn_coeff, alpha, e, h, s));
+    GAT_HIP(hipMemsetAsync(gPL, 0, (size_t)n * HD * sizeof(float), s));
+    EdgeBwdArgs a{};
+    a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
+    a.hpre = d_hpre; a.g = d_g; a.gPL = gPL; a.gPR = gPR; a.ge = nullptr; a.ga_partial = gap; a.ga_blocks = blocks;
+    a.n_rows = n; a.H = h; a.D = d; a.slope = slope;
+    GAT_TRY(launch_edge_backward(a, s));
+    GAT_TRY(launch_reduce_partials_add(gap, blocks, HD, d_grad_a, s));
+    GAT_TRY(launch_grad_w(gPL, gPR, d_x, d_grad_w, scr, n, f, HD, s));
+    if (d_hpre_prev && d_g_prev) GAT_TRY(launch_grad_x(gPL, gPR, d_w, d_hpre_prev, d_g_prev, n, f, HD, slope, s));
+    GAT_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---- measurement -------------------------------------------------------------------------------------------------------
+static const char* kNames[GAT_K_COUNT] = {"project_gemm", "edge_forward", "head_forward", "head_backward",
+                                          "edge_backward", "gpl_sum", "grad_w_gemm", "grad_x_gemm", "misc"};
+const char* gat_kernel_name(int k) { return (k >= 0 && k < GAT_K_COUNT) ? kNames[k] : "?"; }
+int gat_kernel_stats(gat_ctx* c, int k, int64_t* launches, double* total_ms) {
+    if (!c || k < 0 || k >= GAT_K_COUNT) return fail(GAT_E_INVALID, "bad argument");
+    GAT_TRY(flush_events(c));
+    if (launches) *launches = c->k_launches[k];
+    if (total_ms) *total_ms = c->k_ms[k];
+    return 0;
+}
+int gat_kernel_stats_reset(gat_ctx* c) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    GAT_TRY(flush_events(c));
+    for (int k = 0; k < GAT_K_COUNT; ++k) { c->k_launches[k] = 0; c->k_ms[k] = 0.0; }
+    return 0;
+}
+
+int gat_algorithmic_bytes(gat_ctx* c, double* bytes_step, double* per_kernel) {
+    if (!c || !c->have_graph) return fail(GAT_E_STATE, "graph not set");
+    // every tensor the restructured algorithm must move once, fp32 (b = 4).
+    double k[GAT_K_COUNT] = {0};
+    const double N = (double)c->n_rows, E = (double)c->n_edges, b = 4.0;
+    const int L = c->cfg.num_layers;
+    for (int l = 0; l < L; ++l) {
+        const Layer& y = c->layers[l];
+        const double HD = y.HD, H = y.H, F = y.F, Dout = (l == L - 1) ? y.D : y.HD;
+        k[GAT_K_PROJECT] += b * (N * F + 2 * HD * F + 2 * N * HD);
+        k[GAT_K_EDGE_FWD] += 4 * (N + 1) + 4 * E + b * (E * HD + N * HD + E * H + N * HD + N * Dout);
+        k[GAT_K_EDGE_BWD] += 4 * (N + 1) + 4 * E + b * (N * HD + E * HD + N * HD + E * H + E * HD + N * HD);
+        k[GAT_K_GRAD_W] += b * (2 * N * HD + N * F + 2 * HD * F);
+        if (l > 0) k[GAT_K_GRAD_X] += b * (2 * N * HD + 2 * N * F);
+    }
+    const double head = 2.0 * 4.0 * N * ((double)c->layers.back().D + 2.0 * c->cfg.num_classes + 2.0);
+    k[GAT_K_HEAD_FWD] = head / 2; k[GAT_K_HEAD_BWD] = head / 2;
+    double tot = 0;
+    for (int i = 0; i < GAT_K_COUNT; ++i) { tot += k[i]; if (per_kernel) per_kernel[i] = k[i]; }
+    if (bytes_step) *bytes_step = tot;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,468 @@
+// gat_edge_kernels.hip — the edge-centric GATv2 hot path for gfx950 (wave64).
+//
+// Replaces the reference's per-(head,edge) thread kernels (GATv2_edge_based.cu, E:<line>):
+//   forward  a2 edge score E:279-324, a3 max/sum E:326-359, a4 coeff E:362-384,
+//            a5 aggregate E:386-424 (atomicAdd), a6 activation E:426-459
+//   backward a7 grad alpha E:612-651, a8 softmax backward E:654-696 (O(deg^2)),
+//            edge parts of a9 E:698-798 and a10 E:801-874
+//   a1 CSR->COO E:67-84
+// with ONE destination-segmented pass per direction over projected features
+//   PL = X·W_left^T, PR = X·W_right^T   (s[e,h,k] = PL[src,h,k] + PR[dst,h,k]).
+// A wave owns a CSR row: every neighbour row PL[src] is one coalesced H*D-float read, the
+// per-head reductions are DPP/shuffle all-reduces, the softmax is online (single gather of
+// PL[src] per edge), h_pre is written once without atomics, and the softmax backward uses
+//   sum_k galpha_k alpha_k == <g[dst,h,:], h_pre[dst,h,:]>
+// which makes it O(E) and single-pass.
+//
+// HBM layouts: PL/PR/h_pre/g [rows][H*D] f32; alpha, ge [E][H] f32 (edge-major: the H values
+// of an edge are one 4H-byte segment); CSR int32.
+#include "gat_internal.h"
+
+namespace gat {
+namespace {
+
+__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// All-reduce (sum) over aligned groups of D consecutive lanes, D a power of two <= 64.
+// quad_perm xor1, xor2, then row_half_mirror / row_mirror (valid as xor steps because the
+// previous steps made every quad / half-row uniform), then cross-row shuffles.
+template <int D>
+__device__ __forceinline__ float group_sum(float t) {
+    if constexpr (D >= 2) t += dpp_mov<0xB1>(t);     // quad_perm [1,0,3,2]
+    if constexpr (D >= 4) t += dpp_mov<0x4E>(t);     // quad_perm [2,3,0,1]
+    if constexpr (D >= 8) t += dpp_mov<0x141>(t);    // row_half_mirror
+    if constexpr (D >= 16) t += dpp_mov<0x140>(t);   // row_mirror
+    if constexpr (D >= 32) t += __shfl_xor(t, 16);
+    if constexpr (D >= 64) t += __shfl_xor(t, 32);
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1: CSR -> COO.  Reference: thread per row, serial over its edges (hub rows serialise).
+// Here: thread per edge, row found by binary search in row_ptr (load-balanced, coalesced stores).
+// Output identical to the reference: src[e] = col_idx[e], dst[e] = row containing e.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csr_to_coo_kernel(const int32_t* __restrict__ row_ptr,
+                                                         const int32_t* __restrict__ col_idx,
+                                                         int32_t* __restrict__ src,
+                                                         int32_t* __restrict__ dst, int64_t n_rows,
+                                                         int64_t n_edges, int32_t dst_offset) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += stride) {
+        // largest row with row_ptr[row] <= e  (upper_bound - 1; skips empty rows correctly)
+        int64_t lo = 0, hi = n_rows;          // invariant: row_ptr[lo] <= e < row_ptr[hi]
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)row_ptr[mid] <= e) lo = mid; else hi = mid;
+        }
+        src[e] = col_idx[e];
+        dst[e] = (int32_t)lo + dst_offset;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward edge pass, fast path: H*D in {8,16,32,64}, D a power of two.
+// One wave per destination row.  G = 64/HD edges are gathered per wave-instruction (lane ->
+// (group, channel)); U gathers per group are issued back to back before any is consumed.
+// ------------------------------------------------------------------------------------------------
+template <int HD, int D>
+__global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
+    constexpr int G = 64 / HD;      // edges per wave-instruction
+    constexpr int U = 16 / G;       // gathers in flight per group
+    constexpr int CH = 16;          // edges per chunk (= U*G)
+    constexpr int H = HD / D;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= A.n_rows) return;
+    const int c = lane % HD, gidx = lane / HD;
+    const int b = A.row_ptr[row], e_end = A.row_ptr[row + 1];
+    const float pr = A.PR[row * HD + c];
+    const float ac = A.a[c];
+    const float slope = A.slope;
+    float m = -1e9f, Z = 0.f, acc = 0.f;     // E:336 seeds the max with -1e9f
+    const bool multi = (e_end - b) > CH;
+    float sc[U];
+
+    for (int e0 = b; e0 < e_end || e0 == b; e0 += CH) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = e0 + u * G + gidx;
+            const bool valid = j < e_end;
+            const int sid = valid ? A.col_idx[j] : 0;
+            v[u] = valid ? A.PL[(int64_t)sid * HD + c] : 0.f;
+        }
+        float cm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = e0 + u * G + gidx;
+            const float t = group_sum<D>(ac * lrelu(v[u] + pr, slope));
+            sc[u] = (j < e_end) ? t : -INFINITY;
+            cm = fmaxf(cm, sc[u]);
+        }
+        const float mn = fmaxf(m, cm);
+        const float scale = __expf(m - mn);
+        Z *= scale;
+        acc *= scale;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float p = __expf(sc[u] - mn);      // 0 for padded edges
+            Z += p;
+            acc = fmaf(p, v[u], acc);
+        }
+        m = mn;
+        if (multi) {                                 // park raw scores; normalised after the loop
+            if ((c % D) == 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = e0 + u * G + gidx;
+                    if (j < e_end) A.alpha[(int64_t)j * H + c / D] = sc[u];
+                }
+            }
+        }
+        if (e0 + CH >= e_end) break;
+    }
+
+    // merge the G edge groups (online-softmax combine); afterwards all groups agree
+#pragma unroll
+    for (int off = HD; off < 64; off <<= 1) {
+        const float mo = __shfl_xor(m, off), Zo = __shfl_xor(Z, off), ao = __shfl_xor(acc, off);
+        const float mn = fmaxf(m, mo);
+        const float s1 = __expf(m - mn), s2 = __expf(mo - mn);
+        Z = Z * s1 + Zo * s2;
+        acc = acc * s1 + ao * s2;
+        m = mn;
+    }
+    const float denom = Z + 1e-8f;                   // E:379
+    const float hp = acc * (1.0f / denom);
+
+    if (!multi) {                                    // whole row still in registers
+        if ((c % D) == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = b + u * G + gidx;
+                if (j < e_end) A.alpha[(int64_t)j * H + c / D] = __expf(sc[u] - m) / denom;
+            }
+        }
+    } else {
+        // The raw scores were written by other lanes of this wave: drain the stores, then
+        // sweep the row's [deg][H] slice (contiguous) and normalise in place.
+        __threadfence_block();
+        const int total = (e_end - b) * H;
+        float* arow = A.alpha + (int64_t)b * H;
+        for (int i0 = 0; i0 < total; i0 += 64) {
+            const int i = i0 + lane;
+            const int h = i % H;
+            const float mh = __shfl(m, h * D), dh = __shfl(denom, h * D);
+            if (i < total) arow[i] = __expf(arow[i] - mh) / dh;
+        }
+    }
+
+    if (gidx == 0) {
+        A.hpre[row * HD + c] = hp;
+        if ((c % D) == 0 && A.mstat != nullptr) {
+            A.mstat[row * H + c / D] = m;
+            A.zstat[row * H + c / D] = Z;
+        }
+    }
+    const float act = lrelu(hp, slope);
+    if (!A.is_last) {
+        if (gidx == 0) A.hout[row * HD + c] = act;   // concat heads (E:452-457)
+    } else {
+        float t = act;                               // activate, then average heads (E:440-449)
+#pragma unroll
+        for (int off = D; off < HD; off <<= 1) t += __shfl_xor(t, off);
+        if (lane < D) A.hout[row * D + lane] = t / (float)H;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward edge pass, fast path.  Grid-stride over rows (fixed grid so that the per-block
+// grad_a partials stay small).  Per edge: one PL[src] gather, one alpha read, one gPL row add.
+//   galpha = <g[dst,h,:], PL[src,h,:]>                 (E:632-646)
+//   ge     = alpha (galpha - <g[dst,h,:], h_pre[dst,h,:]>)   (≡ E:682-693)
+//   gs     = ge a LReLU'(s)                             (E:774-775)
+//   grad_a += ge LReLU(s)   gPR[dst] += gs   gPL[src] += g alpha + gs   (E:769-782, 859-869)
+// ------------------------------------------------------------------------------------------------
+template <int HD, int D>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
+    constexpr int G = 64 / HD;
+    constexpr int U = 16 / G;
+    constexpr int CH = 16;
+    constexpr int H = HD / D;
+    __shared__ float red[4][HD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane % HD, gidx = lane / HD;
+    const float ac = A.a[c];
+    const float slope = A.slope;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    float ga = 0.f;
+
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < A.n_rows; row += nwaves) {
+        const int b = A.row_ptr[row], e_end = A.row_ptr[row + 1];
+        const float g = A.g[row * HD + c];
+        const float pr = A.PR[row * HD + c];
+        const float dot = group_sum<D>(g * A.hpre[row * HD + c]);
+        float gpr = 0.f;
+        for (int e0 = b; e0 < e_end; e0 += CH) {
+            float v[U], al[U];
+            int sid[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = e0 + u * G + gidx;
+                const bool valid = j < e_end;
+                sid[u] = valid ? A.col_idx[j] : 0;
+                v[u] = valid ? A.PL[(int64_t)sid[u] * HD + c] : 0.f;
+                al[u] = valid ? A.alpha[(int64_t)j * H + c / D] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = e0 + u * G + gidx;
+                const float galpha = group_sum<D>(g * v[u]);
+                const float ge = al[u] * (galpha - dot);        // 0 for padded edges (alpha = 0)
+                const float s = v[u] + pr;
+                const bool pos = s > 0.f;
+                const float gs = ge * ac * (pos ? 1.0f : slope);
+                ga = fmaf(ge, pos ? s : s * slope, ga);
+                gpr += gs;
+                if (j < e_end) {
+                    unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, fmaf(g, al[u], gs));
+                    if (A.ge != nullptr && (c % D) == 0) A.ge[(int64_t)j * H + c / D] = ge;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = HD; off < 64; off <<= 1) gpr += __shfl_xor(gpr, off);
+        if (gidx == 0) A.gPR[row * HD + c] = gpr;
+    }
+#pragma unroll
+    for (int off = HD; off < 64; off <<= 1) ga += __shfl_xor(ga, off);
+    if (gidx == 0) red[wave][c] = ga;
+    __syncthreads();
+    if (threadIdx.x < HD)
+        A.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic (any H, D) forward / backward: one wave per row, head statistics by "lane = head",
+// aggregation by "lane = channel" with a stride-64 loop.  Correctness path for shapes outside the
+// fast path; same math, literal alpha-weighted sums in ascending edge order.
+// dynamic LDS: forward  act[HD];  backward dot[H] ge[H] al[H] ga[HD] gpr[HD]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void edge_fwd_generic(EdgeFwdArgs A) {
+    extern __shared__ float lds[];
+    const int H = A.H, D = A.D, HD = H * D;
+    const int lane = threadIdx.x;
+    const float slope = A.slope;
+    for (int64_t row = blockIdx.x; row < A.n_rows; row += gridDim.x) {
+        const int b = A.row_ptr[row], e_end = A.row_ptr[row + 1];
+        for (int h = lane; h < H; h += 64) {
+            float m = -1e9f;
+            for (int e = b; e < e_end; ++e) {
+                const int64_t sid = A.col_idx[e];
+                float s = 0.f;
+                for (int k = 0; k < D; ++k) {
+                    const int ch = h * D + k;
+                    s += A.a[ch] * lrelu(A.PL[sid * HD + ch] + A.PR[row * HD + ch], slope);
+                }
+                A.alpha[(int64_t)e * H + h] = s;
+                m = fmaxf(m, s);
+            }
+            float Z = 0.f;
+            for (int e = b; e < e_end; ++e) Z += __expf(A.alpha[(int64_t)e * H + h] - m);
+            for (int e = b; e < e_end; ++e) {
+                const int64_t i = (int64_t)e * H + h;
+                A.alpha[i] = __expf(A.alpha[i] - m) / (Z + 1e-8f);
+            }
+            if (A.mstat != nullptr) { A.mstat[row * H + h] = m; A.zstat[row * H + h] = Z; }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int ch = lane; ch < HD; ch += 64) {
+            float acc = 0.f;
+            for (int e = b; e < e_end; ++e) {
+                const int64_t sid = A.col_idx[e];
+                acc += A.alpha[(int64_t)e * H + ch / D] * A.PL[sid * HD + ch];
+            }
+            A.hpre[row * HD + ch] = acc;
+            const float act = lrelu(acc, slope);
+            if (!A.is_last) A.hout[row * HD + ch] = act; else lds[ch] = act;
+        }
+        if (A.is_last) {
+            __syncthreads();
+            for (int k = lane; k < D; k += 64) {
+                float t = 0.f;
+                for (int h = 0; h < H; ++h) t += lds[h * D + k];
+                A.hout[row * D + k] = t / (float)H;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void edge_bwd_generic(EdgeBwdArgs A) {
+    extern __shared__ float lds[];
+    const int H = A.H, D = A.D, HD = H * D;
+    float* s_dot = lds;
+    float* s_ge = lds + H;
+    float* s_al = lds + 2 * H;
+    float* s_ga = lds + 3 * H;
+    float* s_gpr = s_ga + HD;
+    const int lane = threadIdx.x;
+    const float slope = A.slope;
+    for (int ch = lane; ch < HD; ch += 64) s_ga[ch] = 0.f;
+    for (int64_t row = blockIdx.x; row < A.n_rows; row += gridDim.x) {
+        const int b = A.row_ptr[row], e_end = A.row_ptr[row + 1];
+        for (int h = lane; h < H; h += 64) {
+            float t = 0.f;
+            for (int k = 0; k < D; ++k) t += A.g[row * HD + h * D + k] * A.hpre[row * HD + h * D + k];
+            s_dot[h] = t;
+        }
+        for (int ch = lane; ch < HD; ch += 64) s_gpr[ch] = 0.f;
+        __syncthreads();
+        for (int e = b; e < e_end; ++e) {
+            const int64_t sid = A.col_idx[e];
+            for (int h = lane; h < H; h += 64) {
+                float t = 0.f;
+                for (int k = 0; k < D; ++k) t += A.g[row * HD + h * D + k] * A.PL[sid * HD + h * D + k];
+                const float al = A.alpha[(int64_t)e * H + h];
+                const float ge = al * (t - s_dot[h]);
+                s_ge[h] = ge;
+                s_al[h] = al;
+                if (A.ge != nullptr) A.ge[(int64_t)e * H + h] = ge;
+            }
+            __syncthreads();
+            for (int ch = lane; ch < HD; ch += 64) {
+                const float v = A.PL[sid * HD + ch];
+                const float s = v + A.PR[row * HD + ch];
+                const bool pos = s > 0.f;
+                const float ge = s_ge[ch / D];
+                const float gs = ge * A.a[ch] * (pos ? 1.0f : slope);
+                s_ga[ch] += ge * (pos ? s : s * slope);
+                s_gpr[ch] += gs;
+                unsafeAtomicAdd(A.gPL + sid * HD + ch, A.g[row * HD + ch] * s_al[ch / D] + gs);
+            }
+            __syncthreads();
+        }
+        for (int ch = lane; ch < HD; ch += 64) A.gPR[row * HD + ch] = s_gpr[ch];
+        __syncthreads();
+    }
+    for (int ch = lane; ch < HD; ch += 64) A.ga_partial[(int64_t)blockIdx.x * HD + ch] = s_ga[ch];
+}
+
+// [A][B] -> [B][A] elementwise transposes for taps (small / test-only traffic)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src,
+                                                        float* __restrict__ dst, int64_t A_, int64_t B_) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t total = A_ * B_;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t a = i / B_, b = i % B_;     // src[a][b]
+        dst[b * A_ + a] = src[i];
+    }
+}
+
+inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+template <int HD, int D>
+int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
+    const int64_t blocks = (a.n_rows + 3) / 4;
+    hipLaunchKernelGGL((edge_fwd_kernel<HD, D>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+template <int HD, int D>
+int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((edge_bwd_kernel<HD, D>), dim3((unsigned)a.ga_blocks), dim3(256), 0, s, a);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+constexpr int kGenericBlocks = 4096;
+
+}  // namespace
+
+#define GAT_DISPATCH_HD_D(FN, ARGS, S)                                            \
+    switch (HD * 1000 + D) {                                                      \
+        case 64008: return FN<64, 8>(ARGS, S);                                    \
+        case 64004: return FN<64, 4>(ARGS, S);                                    \
+        case 64016: return FN<64, 16>(ARGS, S);                                   \
+        case 64032: return FN<64, 32>(ARGS, S);                                   \
+        case 64064: return FN<64, 64>(ARGS, S);                                   \
+        case 32008: return FN<32, 8>(ARGS, S);                                    \
+        case 32004: return FN<32, 4>(ARGS, S);                                    \
+        case 32016: return FN<32, 16>(ARGS, S);                                   \
+        case 32032: return FN<32, 32>(ARGS, S);                                   \
+        case 16004: return FN<16, 4>(ARGS, S);                                    \
+        case 16008: return FN<16, 8>(ARGS, S);                                    \
+        case 16016: return FN<16, 16>(ARGS, S);                                   \
+        case 8004: return FN<8, 4>(ARGS, S);                                      \
+        case 8008: return FN<8, 8>(ARGS, S);                                      \
+        default: break;                                                           \
+    }
+
+int launch_edge_forward(const EdgeFwdArgs& a, hipStream_t s) {
+    if (a.n_rows <= 0) return 0;
+    const int HD = a.H * a.D, D = a.D;
+    GAT_DISPATCH_HD_D(run_fwd, a, s)
+    const int64_t blocks = a.n_rows < kGenericBlocks * 8 ? a.n_rows : kGenericBlocks * 8;
+    hipLaunchKernelGGL(edge_fwd_generic, dim3((unsigned)blocks), dim3(64), (size_t)HD * sizeof(float), s, a);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+int edge_backward_blocks(int64_t n_rows) {
+    const int64_t want = (n_rows + 3) / 4;
+    return (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+}
+
+int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s) {
+    const int HD = a.H * a.D, D = a.D;
+    if (a.ga_blocks != edge_backward_blocks(a.n_rows)) return fail(GAT_E_INVALID, "edge_backward: ga_blocks mismatch");
+    GAT_DISPATCH_HD_D(run_bwd, a, s)
+    const size_t lds = (size_t)(3 * a.H + 2 * HD) * sizeof(float);
+    if (lds > 64 * 1024) return fail(GAT_E_UNSUPPORTED, "edge_backward: H*D too large for the generic path");
+    hipLaunchKernelGGL(edge_bwd_generic, dim3((unsigned)a.ga_blocks), dim3(64), lds, s, a);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
+                      int64_t n_rows, int64_t n_edges, int64_t dst_offset, hipStream_t s) {
+    if (n_edges <= 0) return 0;
+    int64_t blocks = (n_edges + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(csr_to_coo_kernel, dim3((unsigned)blocks), dim3(256), 0, s, row_ptr, col_idx, src,
+                       dst, n_rows, n_edges, (int32_t)dst_offset);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_transpose(const float* src, float* dst, int64_t A_, int64_t B_, hipStream_t s) {
+    const int64_t total = A_ * B_;
+    if (total <= 0) return 0;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, A_, B_);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+int launch_transpose_eh_to_he(const float* src_eh, float* dst_he, int64_t E, int32_t H, hipStream_t s) {
+    return launch_transpose(src_eh, dst_he, E, H, s);
+}
+int launch_transpose_he_to_eh(const float* src_he, float* dst_eh, int64_t E, int32_t H, hipStream_t s) {
+    return launch_transpose(src_he, dst_eh, H, E, s);
+}
+int launch_transpose_nh_to_hn(const float* src_nh, float* dst_hn, int64_t N, int32_t H, hipStream_t s) {
+    return launch_transpose(src_nh, dst_hn, N, H, s);
+}
+
+}  // namespace gat

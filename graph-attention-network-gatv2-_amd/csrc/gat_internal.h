@@ -1,0 +1,136 @@
+// gat_internal.h — declarations shared by the HIP translation units behind include/gatv2_abi.h.
+// gfx950 (MI355X) only: wave64, fp32 MFMA, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "gatv2_abi.h"
+
+namespace gat {
+
+constexpr int kWave = 64;
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define GAT_HIP(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return ::gat::fail((int)e__, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+#define GAT_TRY(expr)                 \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__ != 0) return rc__;   \
+    } while (0)
+
+// ---- edge-centric kernels (gat_edge_kernels.hip) ------------------------------------------------
+struct EdgeFwdArgs {
+    const int32_t* row_ptr;   // [n_rows+1]
+    const int32_t* col_idx;   // [E] table row ids
+    const float* PL;          // [n_table][HD]
+    const float* PR;          // [n_rows][HD]
+    const float* a;           // [HD]
+    float* alpha;             // [E][H]
+    float* hpre;              // [n_rows][HD]
+    float* hout;              // hidden [n_rows][HD]; last [n_rows][D]
+    float* mstat;             // [n_rows][H] or null (tap)
+    float* zstat;             // [n_rows][H] or null (tap)
+    int64_t n_rows;
+    int32_t H, D;
+    int32_t is_last;
+    float slope;
+};
+int launch_edge_forward(const EdgeFwdArgs& a, hipStream_t s);
+
+struct EdgeBwdArgs {
+    const int32_t* row_ptr;
+    const int32_t* col_idx;
+    const float* PL;          // [n_table][HD]
+    const float* PR;          // [n_rows][HD]
+    const float* a;           // [HD]
+    const float* alpha;       // [E][H]
+    const float* hpre;        // [n_rows][HD]
+    const float* g;           // [n_rows][HD]  dL/dh_pre
+    float* gPL;               // [n_table][HD]  zeroed by the caller, added into
+    float* gPR;               // [n_rows][HD]   written
+    float* ge;                // [E][H] or null (tap)
+    float* ga_partial;        // [ga_blocks][HD] written
+    int32_t ga_blocks;        // grid size the launcher must use (== rows of ga_partial)
+    int64_t n_rows;
+    int32_t H, D;
+    float slope;
+};
+int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s);
+int edge_backward_blocks(int64_t n_rows);   // grid size used by launch_edge_backward
+
+int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
+                      int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);
+
+// out[c] += sum_b partial[b][c]   (deterministic: one thread per c, ascending b)
+int launch_reduce_partials_add(const float* partial, int32_t nblocks, int64_t width, float* out,
+                               hipStream_t s);
+
+// layout converters for taps / op-level entry points
+int launch_transpose_eh_to_he(const float* src_eh, float* dst_he, int64_t E, int32_t H, hipStream_t s);
+int launch_transpose_he_to_eh(const float* src_he, float* dst_eh, int64_t E, int32_t H, hipStream_t s);
+int launch_transpose_nh_to_hn(const float* src_nh, float* dst_hn, int64_t N, int32_t H, hipStream_t s);
+
+// ---- dense kernels (gat_dense_kernels.hip) -------------------------------------------------------
+// PL[table_row0 + i][j] = sum_f X[i][f] * W[j][f],  PR[i][j] = sum_f X[i][f] * W[j][F+f]
+// W in reference layout [HD][2F].
+int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows,
+                   int32_t F, int32_t HD, hipStream_t s);
+// gradW[j][0:F] += sum_n gPL[n][j] X[n][:],  gradW[j][F:2F] += sum_n gPR[n][j] X[n][:]
+// scratch: at least grad_w_scratch_floats(n_rows, F, HD) floats.
+int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);
+int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float* gradW,
+                  float* scratch, int64_t n_rows, int32_t F, int32_t HD, hipStream_t s);
+// gprev[n][f] = (sum_j gPL[n][j] W[j][f] + gPR[n][j] W[j][F+f]) * LReLU'(hpre_prev[n][f])
+int launch_grad_x(const float* gPL_rows, const float* gPR, const float* W, const float* hpre_prev,
+                  float* gprev, int64_t n_rows, int32_t F, int32_t HD, float slope, hipStream_t s);
+
+struct HeadArgs {
+    const float* Wo;          // [C][DL]
+    const float* HL;          // [n_rows][DL]  post-activation last layer output
+    const int32_t* labels;    // [n_rows]
+    float* y;                 // [n_rows][C]
+    double* loss_partial;     // [blocks]
+    int32_t* correct_partial; // [blocks]
+    float* loss_out;          // [1] device
+    int32_t* correct_out;     // [1] device
+    int64_t n_rows;
+    int32_t C, DL;
+};
+int head_blocks(int64_t n_rows);
+int launch_head_forward(const HeadArgs& a, hipStream_t s);
+
+struct HeadBwdArgs {
+    const float* Wo;          // [C][DL]
+    const float* HL;          // [n_rows][DL]
+    const float* y;           // [n_rows][C]
+    const int32_t* labels;
+    const float* hpre;        // last layer pre-activation [n_rows][H][DL]
+    float* g;                 // [n_rows][H][DL]
+    float* gradWo;            // [C][DL] added into
+    float* partial;           // [head_bwd_blocks][C*DL]
+    int64_t n_rows;
+    int32_t C, DL, H;
+    float slope;
+    int32_t flat_index;
+};
+int head_bwd_blocks(int64_t n_rows, int32_t C, int32_t DL);
+int launch_head_backward(const HeadBwdArgs& a, hipStream_t s);
+
+int launch_sgd(float* p, const float* g, float lr, int64_t n, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, float lr, int64_t n, float b1, float b2,
+                float eps, int32_t t, hipStream_t s);
+// per-group clip (E:250-278) with the norm kept on the device; scratch >= 1 float
+int launch_clip(float* g, int64_t n, float thresh, float* scratch, hipStream_t s);
+
+}  // namespace gat

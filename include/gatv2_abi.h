@@ -1,0 +1,179 @@
+/* gatv2_abi.h — C ABI of the MI355X-native GATv2 edge-centric hot path (libgatv2_hip.so).
+ *
+ * The reference (GATv2_edge_based.cu, cited E:<line>) has no FFI/plugin seam: `main` launches
+ * its kernels inline (E:1370-1642).  This header defines the seam at exactly those launch
+ * sites; every entry point names the reference launch(es) it replaces.  Plain C: pointers and
+ * sizes only, no C++/torch types.  All functions return 0 on success, otherwise a non-zero
+ * status (a hipError_t value, or one of GAT_E_*); gat_last_error() gives the message.
+ *
+ * Layouts at the boundary are the REFERENCE layouts:
+ *   W   flat [l][H_l][D_l][2*F_l]  (cols 0..F-1 multiply x_src, F..2F-1 x_dst; E:294-316)
+ *   a   flat [l][H_l][D_l]                                                    (E:296)
+ *   Wo  [C][D_last]                                                           (E:464)
+ *   edge tensors [H][E] head-major (E:297), node tensors [N][H][D] (E:410)
+ * Inside the context tensors live in MI355X-friendly layouts (edge tensors [E][H], projected
+ * features PL/PR [N][H*D]); gat_tap() converts back.
+ *
+ * Threading: a context is not thread-safe; one context per GPU / per rank.
+ * Ownership: the caller owns host arrays and the gat_ctx*; the context owns its device memory
+ * except buffers handed in through gat_bind_table() (borrowed, never freed).
+ */
+#ifndef GATV2_ABI_H
+#define GATV2_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAT_ABI_VERSION 1
+
+enum {
+    GAT_OK = 0,
+    GAT_E_INVALID = 10001,   /* bad argument / shape */
+    GAT_E_STATE = 10002,     /* call order (e.g. forward before set_graph) */
+    GAT_E_NOMEM = 10003,
+    GAT_E_UNSUPPORTED = 10004
+};
+
+typedef struct gat_ctx gat_ctx;
+
+/* Mirrors the reference's CLI model config (E:934-1010, 1115-1118, 1143). */
+typedef struct gat_config {
+    int32_t num_layers;        /* --num-layers */
+    const int32_t* heads;      /* --heads,   [num_layers] */
+    const int32_t* outdims;    /* --outdims, [num_layers] */
+    int32_t in_dim;            /* input_feature_vector_dim (E:1079) */
+    int32_t num_classes;       /* max(label)+1 (E:1107) */
+    float negative_slope;      /* 0.01f (E:1143) */
+    int32_t device;            /* HIP device ordinal */
+    void* stream;              /* hipStream_t to run on; NULL = context creates its own */
+    int32_t flat_lrelu_index;  /* 0 = exact per-head LReLU' in the output gradient (default);
+                                  1 = the reference's flat index n*D+d (E:598) */
+    int32_t collect_timing;    /* 1 = bracket every kernel with hipEvents (gat_kernel_stats) */
+    int32_t keep_taps;         /* 1 = also keep tensors only parity tests read (ge, max, sum) */
+} gat_config;
+
+const char* gat_last_error(void);
+int gat_abi_version(void);
+int gat_device_count(int* count);
+
+/* ---- lifecycle (replaces the inline cudaMalloc plan, E:1151-1357) ------------------------- */
+int gat_create(const gat_config* cfg, gat_ctx** out);
+int gat_destroy(gat_ctx* ctx);
+int gat_sync(gat_ctx* ctx);                       /* wait for the context's stream */
+int gat_mem_info(size_t* free_bytes, size_t* total_bytes);   /* cudaMemGetInfo, E:930, 1362 */
+
+/* ---- data (H2D copies E:1151-1172; CSR->COO E:1186) --------------------------------------
+ * Rows are destinations, columns are sources (E:74-82).  Single GPU: n_table == n_rows,
+ * table_row0 == 0.  Destination-range shard: the context owns rows
+ * [table_row0, table_row0+n_rows) of an n_table-row source table and col_idx holds table row
+ * ids (see INTEGRATION.md "sharding"); host arrays are copied. */
+int gat_set_graph(gat_ctx* ctx, const int32_t* row_ptr, const int32_t* col_idx, int64_t n_rows,
+                  int64_t n_edges, int64_t n_table, int64_t table_row0);
+int gat_set_features(gat_ctx* ctx, const float* x, int64_t n_rows, int32_t in_dim);   /* [n_rows][F0] */
+int gat_set_labels(gat_ctx* ctx, const int32_t* labels, int64_t n_rows);
+/* Device-resident variants (pointers on ctx's device; copied D2D). */
+int gat_set_graph_device(gat_ctx* ctx, const int32_t* d_row_ptr, const int32_t* d_col_idx,
+                         int64_t n_rows, int64_t n_edges, int64_t n_table, int64_t table_row0);
+int gat_set_features_device(gat_ctx* ctx, const float* d_x, int64_t n_rows, int32_t in_dim);
+int gat_set_labels_device(gat_ctx* ctx, const int32_t* d_labels, int64_t n_rows);
+
+/* ---- parameters (Xavier init E:186-248; flat layouts E:1242-1258) --------------------------- */
+enum { GAT_PARAM_W = 0, GAT_PARAM_A = 1, GAT_PARAM_WO = 2 };
+int gat_param_count(gat_ctx* ctx, int group, int64_t* count);
+int gat_params_init(gat_ctx* ctx, uint64_t seed);     /* U(-lim,lim], lim as E:208, 236 */
+int gat_params_set(gat_ctx* ctx, int group, const float* host, int64_t count);
+int gat_params_get(gat_ctx* ctx, int group, float* host, int64_t count);
+int gat_grads_get(gat_ctx* ctx, int group, float* host, int64_t count);
+int gat_grads_set(gat_ctx* ctx, int group, const float* host, int64_t count);
+/* Device address of the packed gradient buffer [gradW | grada | gradWo] (for the all-reduce). */
+int gat_grads_device(gat_ctx* ctx, void** d_ptr, int64_t* count);
+
+/* ---- the step (world == 1): epoch body E:1374-1557 ------------------------------------------- */
+/* forward over all layers + output head + loss; returns sum loss (E:542) and #correct (E:543). */
+int gat_forward(gat_ctx* ctx, float* loss_sum, int32_t* n_correct);
+int gat_backward(gat_ctx* ctx);                   /* E:1463-1557; adds into the grad buffers */
+int gat_zero_grad(gat_ctx* ctx);                  /* E:1631-1637 */
+int gat_clip(gat_ctx* ctx, float threshold);      /* clip_grad_norm x3, E:1561-1567 */
+int gat_step_sgd(gat_ctx* ctx, float lr);         /* E:1601-1624 */
+int gat_step_adam(gat_ctx* ctx, float lr, float beta1, float beta2, float eps, int32_t t);  /* E:1571-1596 */
+
+/* ---- the step in phases (any world size; the host runs the exchange between phases) ---------
+ * forward, layer l:  project -> [all-gather PL table] -> forward_edges
+ * backward, layer l: backward_edges -> [reduce-scatter gPL table] -> backward_dense
+ * after the last backward phase: [all-reduce packed grads, loss scalars]. */
+int gat_layer_project(gat_ctx* ctx, int32_t layer);         /* W_l·x / W_r·x parts of E:1386, 1416 */
+int gat_layer_forward_edges(gat_ctx* ctx, int32_t layer);   /* E:1386, 1398, 1407, 1416, 1428 */
+int gat_head_forward(gat_ctx* ctx, float* loss_sum, int32_t* n_correct);   /* E:1446, 1457, 1460 */
+int gat_head_backward(gat_ctx* ctx);                        /* E:1468 */
+int gat_layer_backward_edges(gat_ctx* ctx, int32_t layer);  /* E:1489, 1503 + edge parts of 1517, 1533 */
+int gat_layer_backward_dense(gat_ctx* ctx, int32_t layer);  /* dense parts of E:1517, 1533; E:1546 */
+
+/* Exchange buffers.  GAT_TABLE_PL: projected source features, [n_table][H_l*D_l] f32, the
+ * context writes rows [table_row0, +n_rows) in gat_layer_project and reads all rows in the edge
+ * phases.  GAT_TABLE_GPL: gradient wrt PL, same shape, the edge backward adds into ALL rows; after
+ * the host's reduce-scatter rows [table_row0, +n_rows) must hold the summed values.
+ * gat_table() returns the context's own buffer; gat_bind_table() substitutes a caller-owned one
+ * (e.g. memory registered with the collective library). */
+enum { GAT_TABLE_PL = 0, GAT_TABLE_GPL = 1 };
+int gat_table(gat_ctx* ctx, int which, int32_t layer, void** d_ptr, int64_t* n_rows, int64_t* row_floats);
+int gat_bind_table(gat_ctx* ctx, int which, int32_t layer, void* d_ptr, int64_t bytes);
+
+/* ---- taps: intermediates converted to the reference layout, for parity tests -----------------
+ * host_dst receives `count` floats (int32 for SRC/DST). */
+enum {
+    GAT_TAP_SRC = 0,        /* int32 [E]             d_src  (E:1186) */
+    GAT_TAP_DST = 1,        /* int32 [E]             d_dst */
+    GAT_TAP_ALPHA = 2,      /* [H][E]                attn_coeff[l] (E:381) */
+    GAT_TAP_HPRE = 3,       /* [N][H][D]             d_h[l] (E:422) */
+    GAT_TAP_HOUT = 4,       /* [N][H*D] | [N][D]     d_layer_outputs[l] (E:449, 456) */
+    GAT_TAP_Y = 5,          /* [N][C]                d_y (E:508) */
+    GAT_TAP_G = 6,          /* [N][H][D]             input_gradients[l] (E:601, 891) */
+    GAT_TAP_GE = 7,         /* [H][E]                grad_attn_score (E:693) */
+    GAT_TAP_MAX = 8,        /* [H][N]                d_max_attn_score (E:356) */
+    GAT_TAP_SUM = 9,        /* [H][N]                d_sum_score_exp (E:357) */
+    GAT_TAP_PL = 10,        /* [n_table][H*D]        W_left·x  (the product's own intermediate) */
+    GAT_TAP_PR = 11         /* [N][H*D]              W_right·x */
+};
+int gat_tap(gat_ctx* ctx, int tensor, int32_t layer, void* host_dst, int64_t count);
+
+/* ---- op-level entry points: one per reference kernel, caller-provided DEVICE pointers in the
+ *      reference layouts (unit parity).  `stream` may be NULL (default stream). ---------------- */
+/* a1  csr_to_coo_kernel E:67-84 */
+int gat_op_csr_to_coo(const int32_t* d_row_ptr, const int32_t* d_col_idx, int32_t* d_src,
+                      int32_t* d_dst, int64_t n_rows, int64_t n_edges, void* stream);
+/* a2-a6 forward of one layer (E:279-459) from reference-layout W,a: writes attn_coeff [H][E],
+ * h_pre [N][H][D], H_out. */
+int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, const float* d_x,
+                         const float* d_w, const float* d_a, float* d_attn_coeff, float* d_hpre,
+                         float* d_hout, int64_t n, int64_t e, int32_t f, int32_t h, int32_t d,
+                         int32_t is_last, float slope, void* stream);
+/* a7-a11 backward of one layer (E:612-893): adds into d_grad_w/d_grad_a; writes g_prev
+ * (= gx ⊙ LReLU'(hpre_prev)) when d_hpre_prev != NULL. */
+int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, const float* d_x,
+                          const float* d_w, const float* d_a, const float* d_attn_coeff,
+                          const float* d_hpre, const float* d_g, float* d_grad_w, float* d_grad_a,
+                          const float* d_hpre_prev, float* d_g_prev, int64_t n, int64_t e,
+                          int32_t f, int32_t h, int32_t d, float slope, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+enum {
+    GAT_K_PROJECT = 0, GAT_K_EDGE_FWD = 1, GAT_K_HEAD_FWD = 2, GAT_K_HEAD_BWD = 3,
+    GAT_K_EDGE_BWD = 4, GAT_K_GPL_SUM = 5, GAT_K_GRAD_W = 6, GAT_K_GRAD_X = 7, GAT_K_MISC = 8,
+    GAT_K_COUNT = 9
+};
+/* Accumulated HIP-event time of kernel class `k` since the last gat_kernel_stats_reset (needs
+ * collect_timing=1).  Synchronises the stream. */
+int gat_kernel_stats(gat_ctx* ctx, int k, int64_t* launches, double* total_ms);
+int gat_kernel_stats_reset(gat_ctx* ctx);
+const char* gat_kernel_name(int k);
+/* Algorithmic HBM bytes of one forward+backward step on this context's shard. */
+int gat_algorithmic_bytes(gat_ctx* ctx, double* bytes_step, double* bytes_per_kernel /* [GAT_K_COUNT] or NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GATV2_ABI_H */

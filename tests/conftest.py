@@ -1,0 +1,45 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as entry  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return entry.load_package()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    o = entry.load_oracle()
+    o.lib()
+    return o
+
+
+def small_graph(rng, n, e, hub=None, empty=(), n_src=None):
+    """Random CSR (rows = destinations) with optional hub row degree and forced-empty rows."""
+    n_src = n if n_src is None else n_src
+    w = rng.random(n) + 0.05
+    w[list(empty)] = 0.0
+    deg = rng.multinomial(e, w / w.sum())
+    if hub is not None:
+        r, d = hub
+        deg[r] = d
+    for r in empty:
+        deg[r] = 0
+    row_ptr = np.zeros(n + 1, np.int32)
+    row_ptr[1:] = np.cumsum(deg)
+    col = np.concatenate([np.sort(rng.integers(0, n_src, size=int(d))) for d in deg]).astype(np.int32) \
+        if row_ptr[-1] > 0 else np.zeros(0, np.int32)
+    return row_ptr, col
