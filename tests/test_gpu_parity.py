@@ -1,0 +1,180 @@
+"""GPU parity: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same
+seeded inputs.  Tolerances (north_star): CSR->COO bit-exact; attention / h_pre / y / loss 1e-4;
+gradients 1e-4 (fp32 order effects: 1e-3) of the tensor's max-abs."""
+import numpy as np
+import pytest
+
+from conftest import small_graph
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+GTOL = 1e-3
+
+
+def _inputs(orc, seed, n, e, heads, outdims, f, c, hub=None, empty=()):
+    rng = np.random.default_rng(seed)
+    rp, ci = small_graph(rng, n, e, hub=hub, empty=empty)
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    lab = rng.integers(0, c, n).astype(np.int32)
+    lab[0] = c - 1
+    cfg = orc.Config(list(heads), list(outdims), f, c)
+    W, a, Wo = orc.xavier_params(cfg, seed + 1)
+    return cfg, rp, ci, lab, x, W, a, Wo
+
+
+def _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo, **kw):
+    A = pkg.abi
+    ctx = pkg.GatContext(cfg.heads, cfg.outdims, cfg.in_dim0, cfg.num_classes, keep_taps=True, **kw)
+    ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
+    ctx.params_set(A.PARAM_W, W); ctx.params_set(A.PARAM_A, a); ctx.params_set(A.PARAM_WO, Wo)
+    ctx.zero_grad()
+    loss, correct = ctx.forward()
+    ctx.backward()
+    return ctx, loss, correct
+
+
+def _relerr(got, ref):
+    return float(np.abs(got - ref).max() / max(1e-6, np.abs(ref).max()))
+
+
+CASES = [
+    # heads, outdims, F, N, E, hub(row,deg), empty rows        -- E never a multiple of 64/256 (Q3)
+    ((8, 8), (8, 8), 100, 300, 4001, (5, 700), (0, 17, 299)),   # the bench preset, fast path HD=64
+    ((8, 1), (8, 8), 64, 257, 2999, (100, 300), (3,)),          # P-parity preset; last layer HD=8
+    ((4, 4), (8, 8), 128, 200, 1777, (9, 65), ()),              # HD=32 (config 5 shape)
+    ((3, 1), (4, 8), 5, 64, 333, (2, 70), (0, 63)),             # generic path: H=3
+    ((1, 2), (64, 8), 33, 90, 555, None, (1,)),                 # HD=64,D=64 then HD=16
+    ((8, 8, 8), (8, 8, 8), 128, 150, 1203, (7, 260), (0,)),     # 3 layers (Arxiv preset)
+    ((2, 2), (64, 16), 20, 70, 410, (3, 33), ()),               # HD=128: generic path, multi-slot
+]
+
+
+@pytest.mark.parametrize("heads,outdims,f,n,e,hub,empty", CASES)
+def test_step_parity(pkg, orc, heads, outdims, f, n, e, hub, empty):
+    A = pkg.abi
+    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 1234 + n, n, e, heads, outdims, f, 7, hub, empty)
+    ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+    ctx, loss, correct = _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo)
+    try:
+        # a1: bit-exact
+        assert np.array_equal(ctx.tap(A.TAP_SRC), ref.src)
+        assert np.array_equal(ctx.tap(A.TAP_DST), ref.dst)
+        for l in range(cfg.L):
+            assert np.abs(ctx.tap(A.TAP_ALPHA, l) - ref.taps["alpha"][l]).max() < TOL, f"alpha l={l}"
+            assert _relerr(ctx.tap(A.TAP_HPRE, l), ref.taps["hpre"][l]) < TOL, f"hpre l={l}"
+            assert _relerr(ctx.tap(A.TAP_HOUT, l), ref.taps["H"][l]) < TOL, f"H l={l}"
+            assert _relerr(ctx.tap(A.TAP_SUM, l), ref.taps["sum"][l]) < TOL
+            assert np.allclose(ctx.tap(A.TAP_MAX, l), ref.taps["max"][l], rtol=1e-5, atol=1e-5)
+        assert np.abs(ctx.tap(A.TAP_Y) - ref.y).max() < TOL
+        assert abs(loss - ref.loss_sum_f64) / n < TOL
+        assert correct == ref.n_correct
+        for l in range(cfg.L - 1, -1, -1):
+            assert _relerr(ctx.tap(A.TAP_G, l), ref.taps["g"][l]) < GTOL, f"g l={l}"
+            assert _relerr(ctx.tap(A.TAP_GE, l), ref.taps["ge"][l]) < GTOL, f"ge l={l}"
+        assert _relerr(ctx.grads_get(A.PARAM_WO), ref.gradWo) < GTOL
+        assert _relerr(ctx.grads_get(A.PARAM_A), ref.grada) < GTOL
+        assert _relerr(ctx.grads_get(A.PARAM_W), ref.gradW) < GTOL
+    finally:
+        ctx.close()
+
+
+def test_flat_lrelu_index_mode(pkg, orc):
+    """the reference's flat LReLU' index, reproduced on request."""
+    A = pkg.abi
+    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 77, 120, 901, (4, 3), (8, 8), 24, 5)
+    ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo, flat_lrelu_index=True)
+    ctx, _, _ = _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo, flat_lrelu_index=True)
+    try:
+        assert _relerr(ctx.grads_get(A.PARAM_W), ref.gradW) < GTOL
+        assert _relerr(ctx.grads_get(A.PARAM_A), ref.grada) < GTOL
+    finally:
+        ctx.close()
+
+
+def test_grads_accumulate_and_zero(pkg, orc):
+    """Reference contract: grad buffers are added into and memset per epoch (E:1631-1633)."""
+    A = pkg.abi
+    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 5, 100, 700, (8, 8), (8, 8), 16, 4)
+    ctx, _, _ = _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo)
+    try:
+        g1 = ctx.grads_get(A.PARAM_W).copy()
+        ctx.forward(); ctx.backward()
+        g2 = ctx.grads_get(A.PARAM_W)
+        assert np.allclose(g2, 2 * g1, rtol=1e-3, atol=1e-5 * np.abs(g1).max())
+        ctx.zero_grad()
+        assert np.all(ctx.grads_get(A.PARAM_W) == 0)
+    finally:
+        ctx.close()
+
+
+def test_optimizers_and_clip(pkg, orc):
+    A = pkg.abi
+    L = orc.lib()
+    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 6, 80, 500, (8, 1), (8, 8), 12, 3)
+    ctx, _, _ = _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo)
+    try:
+        gW = ctx.grads_get(A.PARAM_W).copy(); ga = ctx.grads_get(A.PARAM_A).copy(); gWo = ctx.grads_get(A.PARAM_WO).copy()
+        ctx.clip(0.05)
+        for grp, g in ((A.PARAM_W, gW), (A.PARAM_A, ga), (A.PARAM_WO, gWo)):
+            L.orc_clip_grad_norm(g, g.size, 0.05)
+            assert _relerr(ctx.grads_get(grp), g) < 1e-4
+        ctx.step_adam(0.01, 0.9, 0.999, 1e-8, 1)
+        for grp, p, g in ((A.PARAM_W, W.copy(), gW), (A.PARAM_A, a.copy(), ga), (A.PARAM_WO, Wo.copy(), gWo)):
+            m = np.zeros_like(p); v = np.zeros_like(p)
+            L.orc_adam(p, g, m, v, 0.01, p.size, 0.9, 0.999, 1e-8, 1)
+            assert np.abs(ctx.params_get(grp) - p).max() < 1e-5
+        ctx.step_sgd(0.5)
+        p = ctx.params_get(A.PARAM_A)
+        assert np.isfinite(p).all()
+    finally:
+        ctx.close()
+
+
+def test_op_level_entry_points(pkg, orc):
+    """a1 and one layer fwd/bwd through the op-level ABI with caller-owned device buffers."""
+    import ctypes as C
+    import torch
+    A = pkg.abi
+    lib = A.load_library()
+    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 21, 130, 1111, (8, 1), (8, 8), 40, 3, hub=(4, 200))
+    ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+    dev = torch.device("cuda:0")
+    t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    d_rp, d_ci, d_x = t(rp), t(ci), t(x)
+    n, e, f, H, D = 130, len(ci), 40, 8, 8
+    d_src = torch.empty(e, dtype=torch.int32, device=dev); d_dst = torch.empty_like(d_src)
+    p = lambda tt: C.c_void_p(tt.data_ptr())
+    assert lib.gat_op_csr_to_coo(p(d_rp), p(d_ci), p(d_src), p(d_dst), n, e, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_src.cpu().numpy(), ref.src) and np.array_equal(d_dst.cpu().numpy(), ref.dst)
+    Wl = t(W[cfg.w_offsets[0]:cfg.w_offsets[1]]); al = t(a[cfg.a_offsets[0]:cfg.a_offsets[1]])
+    d_alpha = torch.empty(H * e, device=dev); d_hpre = torch.empty(n * H * D, device=dev); d_hout = torch.empty(n * H * D, device=dev)
+    rc = lib.gat_op_layer_forward(p(d_rp), p(d_ci), p(d_x), p(Wl), p(al), p(d_alpha), p(d_hpre), p(d_hout), n, e, f, H, D, 0,
+                                  C.c_float(0.01), None)
+    assert rc == 0, lib.gat_last_error()
+    assert np.abs(d_alpha.cpu().numpy().reshape(H, e) - ref.taps["alpha"][0]).max() < TOL
+    assert _relerr(d_hpre.cpu().numpy().reshape(n, H, D), ref.taps["hpre"][0]) < TOL
+    # backward of layer 0 given the oracle's upstream gradient
+    d_g = t(ref.taps["g"][0].reshape(-1)); gw = torch.zeros_like(Wl); ga = torch.zeros_like(al)
+    rc = lib.gat_op_layer_backward(p(d_rp), p(d_ci), p(d_x), p(Wl), p(al), p(d_alpha), p(d_hpre), p(d_g), p(gw), p(ga),
+                                   None, None, n, e, f, H, D, C.c_float(0.01), None)
+    assert rc == 0, lib.gat_last_error()
+    assert _relerr(gw.cpu().numpy(), ref.gradW[cfg.w_offsets[0]:cfg.w_offsets[1]]) < GTOL
+    assert _relerr(ga.cpu().numpy(), ref.grada[cfg.a_offsets[0]:cfg.a_offsets[1]]) < GTOL
+
+
+def test_error_paths(pkg):
+    A = pkg.abi
+    with pytest.raises(A.GatError):
+        pkg.GatContext([8, 8], [8, 8], 0, 3)                      # in_dim must be > 0
+    ctx = pkg.GatContext([8, 8], [8, 8], 4, 3)
+    try:
+        with pytest.raises(A.GatError):
+            ctx.forward()                                          # no graph yet
+        with pytest.raises(A.GatError):
+            ctx.set_graph(np.array([0, 2, 1], np.int32), np.array([0, 0], np.int32))   # Invalid row_ptr
+        with pytest.raises(A.GatError):
+            ctx.set_labels(np.array([0, 5], np.int32))             # label outside classes
+    finally:
+        ctx.close()
