@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — edges/sec of one GATv2 forward+backward step (hot path of GATv2_edge_based.cu) on
+N MI355X, on the OGBN-Products-shape synthetic power-law graph BASELINE.json quotes the metric on.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward over all layers + output head + loss (scalars read back) + backward over all
+layers; optimizer / zero-grad excluded.  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel class, timed live with
+HIP events on the context's stream inside the timed steps; `cpu_baseline` is the literal CPU
+restatement of the reference's algorithm (oracle/) on a bounded sample of the same graph law.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+PRESETS = {   # workload -> (heads, outdims); BASELINE.json gives layer/head counts, SURVEY §8 fixes outdims
+    "products": ([8, 8], [8, 8]),
+    "pubmed": ([8, 8], [8, 8]),
+    "cora": ([8, 8], [8, 8]),
+    "arxiv": ([8, 8, 8], [8, 8, 8]),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="products", choices=sorted(PRESETS))
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink nodes and edges (debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0 = auto (~15 s of CPU work)")
+    ap.add_argument("--backend", default="nccl")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, workload, heads, outdims, sample_scale):
+    """Literal reference algorithm (per-edge W·x recomputation, O(deg^2) softmax backward) on the
+    host cores, on a scaled-down graph of the same law.  Reported, never the target."""
+    orc = entry.load_oracle()
+    n_full, e_full, f, c, kind = pkg.synth.SHAPES[workload]
+
+    def run(scale):
+        ds = pkg.synth.make_dataset(workload, scale=scale)
+        cfg = orc.Config(heads, outdims, ds["f"], ds["c"])
+        W, a, Wo = orc.xavier_params(cfg, 42)
+        t0 = time.perf_counter()
+        orc.step(cfg, ds["row_ptr"], ds["col_idx"], ds["labels"], ds["x"], W, a, Wo, mt_baseline=True)
+        return ds, time.perf_counter() - t0
+
+    if sample_scale <= 0:
+        probe_scale = min(1.0, max(2000.0 / e_full, 1e-4))
+        ds, t = run(probe_scale)                       # calibrate on ~2k edges
+        per_edge = max(t / ds["e"], 1e-9)
+        sample_scale = min(1.0, 15.0 / (per_edge * e_full))
+    ds, t = run(sample_scale)
+    return {
+        "value": ds["e"] / t, "unit": "edges/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
+        "sample": f"{workload}-law graph scaled to {ds['n']} nodes / {ds['e']} edges / {ds['f']} feat, "
+                  f"1 step fwd+bwd in {t:.2f} s (oracle literal mode, OpenMP)",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch
+    pkg = entry.load_package()
+    A = pkg.abi
+    heads, outdims = PRESETS[args.workload]
+    n, e, f, c, kind = pkg.synth.SHAPES[args.workload]
+    if args.scale != 1.0:
+        n, e = max(16, int(n * args.scale)), max(16, int(e * args.scale))
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+
+    # ---- synthetic inputs (same on every rank; each keeps its destination range) ----
+    t_gen = time.perf_counter()
+    row_ptr, col_idx = pkg.synth.powerlaw_graph(n, e)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ctx = pkg.GatContext(heads, outdims, f, c, device=local_rank, stream=stream.cuda_stream, collect_timing=True)
+        if world == 1:
+            ctx.set_graph(row_ptr, col_idx)
+            ctx.set_features(pkg.synth.features(n, f, kind=kind))
+            ctx.set_labels(pkg.synth.labels(n, c))
+            runner = None
+        else:
+            S = pkg.shard
+            plan = S.make_plan(row_ptr, world, rank)
+            rp_l, ci_l = S.local_csr(plan, row_ptr, col_idx)
+            lo, hi = plan.row0, plan.row0 + plan.n_rows
+            ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
+            ctx.set_features(pkg.synth.features(n, f, rows=(lo, hi), kind=kind))
+            ctx.set_labels(pkg.synth.labels(n, c, rows=(lo, hi)))
+            comm = S.TorchComm()
+            runner = S.ShardedGat(ctx, plan, comm, heads, outdims,
+                                  alloc=lambda k: torch.empty(k, dtype=torch.float32, device=dev))
+        del row_ptr, col_idx
+        ctx.params_init(42)
+        ctx.zero_grad()
+        t_gen = time.perf_counter() - t_gen
+
+        def step():
+            if runner is None:
+                out = ctx.forward()
+                ctx.backward()
+            else:
+                out = runner.forward()
+                runner.backward()
+            return out
+
+        for _ in range(args.warmup):
+            step()
+        ctx.zero_grad()
+        ctx.kernel_stats_reset()
+
+        def fence():
+            ctx.sync()
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize(dev)
+
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, correct = step()
+        fence()
+        dt = time.perf_counter() - t0
+        stats = ctx.kernel_stats()
+        bytes_step, bytes_k = ctx.algorithmic_bytes()
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        bt = torch.tensor([bytes_step], dtype=torch.float64, device=dev)
+        dist.all_reduce(bt)
+        bytes_step_all = float(bt.item())
+    else:
+        bytes_step_all = bytes_step
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        dom = max((k for k in stats if stats[k][0] > 0 and k != "misc"), key=lambda k: stats[k][1])
+        launches, tot_ms = stats[dom]
+        per_launch_bytes = bytes_k[dom] * args.steps / launches
+        avg_ms = tot_ms / launches
+        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "edges/sec (fwd+bwd, 2-layer 8-head GATv2)" if len(heads) == 2 else
+                      f"edges/sec (fwd+bwd, {len(heads)}-layer 8-head GATv2)",
+            "value": e / (dt / args.steps), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}-shape synthetic power-law graph, {n} nodes / {e} edges / {f} feat / "
+                            f"{c} classes, {len(heads)}-layer GATv2 heads {heads} outdims {outdims}, fp32",
+                "parallelism": f"dst-range x{world}" if world > 1 else "single GPU",
+                "loss_per_node": loss / n, "setup_s": round(t_gen, 1),
+            },
+            "step_roofline": {"algorithmic_GB_per_step": bytes_step_all / 1e9,
+                              "achieved_GBps": bytes_step_all / (dt / args.steps) / 1e9 / world,
+                              "frac_of_8TBps_per_gpu": bytes_step_all / (dt / args.steps) / 1e9 / world / HBM_PEAK_GBS},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
+            "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in stats.items() if v[0] > 0},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pkg, args.workload, heads, outdims, args.cpu_sample_scale)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

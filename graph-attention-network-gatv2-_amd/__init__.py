@@ -7,5 +7,5 @@ Contents: ``csrc/`` HIP kernels + C ABI (libgatv2_hip.so), ``host/`` the C++ ``t
 drop-in, ``abi.py`` ctypes binding, ``synth.py`` synthetic datasets, ``shard.py`` destination-range
 sharding over torch.distributed.  No CPU fallback exists here by design.
 """
-from . import abi, synth  # noqa: F401
+from . import abi, shard, synth  # noqa: F401
 from .abi import GatContext, GatError, GatLibraryError  # noqa: F401

@@ -116,6 +116,8 @@ def _declare(lib: C.CDLL) -> None:
         "gat_grads_get": [vp, C.c_int, vp, i64],
         "gat_grads_set": [vp, C.c_int, vp, i64],
         "gat_grads_device": [vp, P(vp), P(i64)],
+        "gat_grads_export": [vp, vp, i64],
+        "gat_grads_import": [vp, vp, i64],
         "gat_forward": [vp, P(f32), P(i32)],
         "gat_backward": [vp],
         "gat_zero_grad": [vp],
@@ -271,6 +273,16 @@ class GatContext:
         p, n = C.c_void_p(), C.c_int64()
         _chk(self.lib.gat_grads_device(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def grads_export(self, d_dst: int, count: int):
+        _chk(self.lib.gat_grads_export(self._ctx, C.c_void_p(d_dst), count))
+
+    def grads_import(self, d_src: int, count: int):
+        _chk(self.lib.gat_grads_import(self._ctx, C.c_void_p(d_src), count))
+
+    @property
+    def n_params(self) -> int:
+        return self.param_count(PARAM_W) + self.param_count(PARAM_A) + self.param_count(PARAM_WO)
 
     # -- step
     def forward(self, want_loss: bool = True):

@@ -376,6 +376,19 @@ int gat_grads_device(gat_ctx* c, void** d_ptr, int64_t* count) {
     return 0;
 }
 
+int gat_grads_export(gat_ctx* c, void* d_dst, int64_t count) {
+    if (!c || !d_dst) return fail(GAT_E_INVALID, "null argument");
+    if (count != c->nW + c->nA + c->nWo) return fail(GAT_E_INVALID, "packed gradient size mismatch");
+    GAT_HIP(hipMemcpyAsync(d_dst, c->grads, count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+int gat_grads_import(gat_ctx* c, const void* d_src, int64_t count) {
+    if (!c || !d_src) return fail(GAT_E_INVALID, "null argument");
+    if (count != c->nW + c->nA + c->nWo) return fail(GAT_E_INVALID, "packed gradient size mismatch");
+    GAT_HIP(hipMemcpyAsync(c->grads, d_src, count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
 int gat_params_init(gat_ctx* c, uint64_t seed) {
     if (!c) return fail(GAT_E_INVALID, "null context");
     // Same distribution as xavier_init_kernel_curand (E:205-242); own counter-based stream, since

@@ -1,0 +1,181 @@
+"""Destination-range sharding of the GATv2 step across the GPUs of one node.
+
+One process per GPU.  All in-edges of a destination live in one CSR row, so score, softmax,
+aggregation and every per-destination gradient are local to the row's owner; only source-side
+data crosses shards, once per layer and direction:
+
+    forward  layer l : project own rows -> ALL-GATHER the PL table        -> edge forward
+    backward layer l : edge backward (adds into the full gPL table)
+                       -> REDUCE-SCATTER the gPL table                    -> dense backward
+    end of backward  : ALL-REDUCE of the packed parameter gradients (+ loss, #correct)
+
+The reference has no distributed code at all (single process, default stream); this is the build's
+own scaling axis.  Rows are split on ``row_ptr`` so every rank holds ~E/P edges (power-law graphs
+are edge-, not node-balanced).  Rank p's rows are padded to ``max_rows`` so that the exchange
+tables are plain ``[P][max_rows][H*D]`` arrays: source ids are remapped ONCE to table rows
+``owner*max_rows + local`` and both collectives become the fixed-count, in-place forms
+(``all_gather_into_tensor`` / ``reduce_scatter_tensor``) that RCCL runs as direct xGMI exchanges.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+
+@dataclass
+class ShardPlan:
+    world: int
+    rank: int
+    bounds: np.ndarray        # [world+1] global row boundaries
+    max_rows: int
+
+    @property
+    def row0(self) -> int:
+        return int(self.bounds[self.rank])
+
+    @property
+    def n_rows(self) -> int:
+        return int(self.bounds[self.rank + 1] - self.bounds[self.rank])
+
+    @property
+    def n_table(self) -> int:
+        return self.world * self.max_rows
+
+    @property
+    def table_row0(self) -> int:
+        return self.rank * self.max_rows
+
+    def to_table_ids(self, src_global: np.ndarray) -> np.ndarray:
+        owner = np.searchsorted(self.bounds, src_global, side="right") - 1
+        return (owner.astype(np.int64) * self.max_rows + (src_global - self.bounds[owner])).astype(np.int32)
+
+    def from_table_ids(self, tid: np.ndarray) -> np.ndarray:
+        owner = tid // self.max_rows
+        return (self.bounds[owner] + tid % self.max_rows).astype(np.int32)
+
+
+def edge_balanced_bounds(row_ptr: np.ndarray, world: int) -> np.ndarray:
+    """Row boundaries such that every shard holds ~E/world edges and at least one row."""
+    n = len(row_ptr) - 1
+    e = int(row_ptr[-1])
+    if world > n:
+        raise ValueError("more ranks than rows")
+    targets = (np.arange(1, world, dtype=np.float64) * e / world)
+    cuts = np.searchsorted(row_ptr, targets, side="left").astype(np.int64)
+    b = np.concatenate([[0], cuts, [n]])
+    for p in range(1, world + 1):                       # strictly increasing
+        b[p] = max(b[p], b[p - 1] + 1)
+    for p in range(world - 1, -1, -1):
+        b[p] = min(b[p], b[p + 1] - 1)
+    return b
+
+
+def make_plan(row_ptr: np.ndarray, world: int, rank: int) -> ShardPlan:
+    b = edge_balanced_bounds(np.asarray(row_ptr), world)
+    return ShardPlan(world, rank, b, int(np.diff(b).max()))
+
+
+def local_csr(plan: ShardPlan, row_ptr: np.ndarray, col_idx: np.ndarray):
+    """-> (row_ptr_local int32[n_rows+1], col_idx_local int32 as TABLE row ids)"""
+    s, t = plan.row0, plan.row0 + plan.n_rows
+    e0, e1 = int(row_ptr[s]), int(row_ptr[t])
+    rp = (np.asarray(row_ptr[s:t + 1], np.int64) - e0).astype(np.int32)
+    ci = plan.to_table_ids(np.asarray(col_idx[e0:e1], np.int64))
+    return rp, ci
+
+
+class TorchComm:
+    """The three exchanges over torch.distributed.  backend "nccl" (= RCCL over xGMI): in place on
+    device tensors.  Any other backend (gloo, used by the CPU tests and the 2-ranks-on-one-GPU
+    test): staged through host tensors, all-reduce standing in for reduce-scatter."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.native = dist.get_backend(group) == "nccl"
+
+    def all_gather_rows(self, table, row_floats: int):
+        """table: flat tensor [world*max_rows*row_floats]; rank's slice already filled."""
+        t = table.view(self.world, -1)
+        if self.native:
+            self.dist.all_gather_into_tensor(table, t[self.rank], group=self.group)
+            return
+        mine = t[self.rank].cpu().contiguous()
+        parts = [mine.new_empty(mine.shape) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        for p, part in enumerate(parts):
+            if p != self.rank:
+                t[p].copy_(part)
+
+    def reduce_scatter_rows(self, table, row_floats: int):
+        """table: every rank's full-length partial sums; afterwards rank's slice holds the total."""
+        t = table.view(self.world, -1)
+        if self.native:
+            self.dist.reduce_scatter_tensor(t[self.rank], table, group=self.group)
+            return
+        host = table.cpu()
+        self.dist.all_reduce(host, group=self.group)
+        t[self.rank].copy_(host.view(self.world, -1)[self.rank])
+
+    def all_reduce_(self, tensor):
+        if self.native:
+            self.dist.all_reduce(tensor, group=self.group)
+            return tensor
+        host = tensor.cpu()
+        self.dist.all_reduce(host, group=self.group)
+        tensor.copy_(host)
+        return tensor
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+class ShardedGat:
+    """Host-side driver of one rank: same step as ``GatContext.forward/backward`` but with the
+    exchange steps between the phases.  ``ctx`` is a GatContext (or any object with the same phase
+    API — the CPU tests drive this class with a numpy stand-in to check the exchange logic);
+    ``tables`` maps (which, layer) -> flat torch tensor bound to the context."""
+
+    def __init__(self, ctx, plan: ShardPlan, comm, heads: Sequence[int], outdims: Sequence[int],
+                 alloc: Callable[[int], "object"]):
+        self.ctx, self.plan, self.comm = ctx, plan, comm
+        self.hd = [int(h) * int(d) for h, d in zip(heads, outdims)]
+        self.L = len(self.hd)
+        self.pl = []
+        for l in range(self.L):
+            t = alloc(plan.n_table * self.hd[l])
+            ctx.bind_table(0, l, t.data_ptr(), t.numel() * 4)
+            self.pl.append(t)
+        self.gpl = alloc(plan.n_table * max(self.hd))
+        ctx.bind_table(1, 0, self.gpl.data_ptr(), self.gpl.numel() * 4)
+        self.grads = alloc(ctx.n_params)          # staging buffer for the gradient all-reduce
+
+    def forward(self):
+        """-> (global loss sum, global #correct)"""
+        import torch
+        for l in range(self.L):
+            self.ctx.layer_project(l)
+            self.comm.all_gather_rows(self.pl[l], self.hd[l])
+            self.ctx.layer_forward_edges(l)
+        loss, correct = self.ctx.head_forward()
+        s = torch.tensor([loss, float(correct)], dtype=torch.float64)
+        if getattr(self.comm, "native", False):
+            s = s.to(self.gpl.device)
+        self.comm.all_reduce_(s)
+        return float(s[0]), int(round(float(s[1])))
+
+    def backward(self):
+        self.ctx.head_backward()
+        for l in range(self.L - 1, -1, -1):
+            self.ctx.layer_backward_edges(l)
+            self.comm.reduce_scatter_rows(self.gpl[: self.plan.n_table * self.hd[l]], self.hd[l])
+            self.ctx.layer_backward_dense(l)
+        # W/a/Wo gradients: one packed buffer (tens of KB: latency-bound, a single all-reduce)
+        self.ctx.grads_export(self.grads.data_ptr(), self.grads.numel())
+        self.comm.all_reduce_(self.grads)
+        self.ctx.grads_import(self.grads.data_ptr(), self.grads.numel())

@@ -91,6 +91,10 @@ int gat_grads_get(gat_ctx* ctx, int group, float* host, int64_t count);
 int gat_grads_set(gat_ctx* ctx, int group, const float* host, int64_t count);
 /* Device address of the packed gradient buffer [gradW | grada | gradWo] (for the all-reduce). */
 int gat_grads_device(gat_ctx* ctx, void** d_ptr, int64_t* count);
+/* Async D2D copies of the packed gradients on the context's stream, to / from a caller-owned
+ * device buffer of `count` floats (the buffer the host all-reduces). */
+int gat_grads_export(gat_ctx* ctx, void* d_dst, int64_t count);
+int gat_grads_import(gat_ctx* ctx, const void* d_src, int64_t count);
 
 /* ---- the step (world == 1): epoch body E:1374-1557 ------------------------------------------- */
 /* forward over all layers + output head + loss; returns sum loss (E:542) and #correct (E:543). */
