@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -54,6 +55,9 @@ struct gat_ctx {
     int32_t HDmax = 0, Hmax = 0;
     float* gPL = nullptr; bool gPL_bound = false;   // [n_table][HDmax]
     float* gPR = nullptr;                           // [n_rows][HDmax]
+    int32_t* csc_pos = nullptr;                     // [E] slot of each CSR edge in source-major order
+    int32_t* csc_ptr = nullptr;                     // [n_table+1]
+    float* msg = nullptr; int32_t msg_hd = 0;       // [E][msg_hd] per-edge message rows (store path)
     float* ga_partial = nullptr; int32_t ga_blocks = 0;
     float* gw_scratch = nullptr;
     float* hb_partial = nullptr;
@@ -158,6 +162,24 @@ static int ensure_buffers(gat_ctx* c) {
     }
     if (!c->gPL_bound) GAT_TRY(dalloc(c, &c->gPL, T * c->HDmax));
     GAT_TRY(dalloc(c, &c->gPR, N * c->HDmax));
+    // Store-then-sum backward for the layers on the wave-per-row fast path: needs the source-major
+    // slot index and an [E][H*D] scratch.  GAT_BWD_ATOMICS=1 forces the float-atomic variant (A/B).
+    int32_t msg_hd = 0;
+    for (int l = 0; l < L; ++l)
+        if (edge_fast_path(c->layers[l].H, c->layers[l].D)) msg_hd = std::max(msg_hd, c->layers[l].HD);
+    const char* force = getenv("GAT_BWD_ATOMICS");
+    if (msg_hd > 0 && E > 0 && !(force && force[0] == '1')) {
+        float* m = nullptr;
+        if (hipMalloc((void**)&m, (size_t)E * msg_hd * sizeof(float)) == hipSuccess) {
+            c->owned.push_back(m);
+            c->msg = m; c->msg_hd = msg_hd;
+            GAT_TRY(dalloc(c, &c->csc_pos, E));
+            GAT_TRY(dalloc(c, &c->csc_ptr, T + 1));
+            GAT_TRY(build_csc(c->col_idx, E, T, c->csc_pos, c->csc_ptr, c->stream));
+        } else {
+            (void)hipGetLastError();      // not enough HBM for the scratch: atomics variant
+        }
+    }
     c->ga_blocks = edge_backward_blocks(N);
     GAT_TRY(dalloc(c, &c->ga_partial, (int64_t)c->ga_blocks * c->HDmax));
     int64_t gw = 1;
@@ -469,18 +491,24 @@ int gat_head_backward(gat_ctx* c) {
 int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     GAT_TRY(check_layer(c, l));
     Layer& y = c->layers[l];
-    {
+    const bool store = c->msg != nullptr && edge_fast_path(y.H, y.D);
+    if (!store) {
         Scope t(c, GAT_K_MISC);
         GAT_HIP(hipMemsetAsync(c->gPL, 0, (size_t)c->n_table * y.HD * sizeof(float), c->stream));
     }
     EdgeBwdArgs a{};
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
     a.alpha = y.alpha; a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge;
+    a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
     a.ga_partial = c->ga_partial; a.ga_blocks = c->ga_blocks; a.n_rows = c->n_rows; a.H = y.H; a.D = y.D;
     a.slope = c->cfg.negative_slope;
     {
         Scope t(c, GAT_K_EDGE_BWD);
         GAT_TRY(launch_edge_backward(a, c->stream));
+    }
+    if (store) {
+        Scope t(c, GAT_K_GPL_SUM);
+        GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, y.HD, c->stream));
     }
     Scope t(c, GAT_K_MISC);
     return launch_reduce_partials_add(c->ga_partial, c->ga_blocks, y.HD, ga_of(c, l), c->stream);

@@ -1,0 +1,128 @@
+// gat_csc.hip — source-major (CSC) slot index for the backward scatter, built once per graph.
+//
+// The reference scatters per-edge gradient contributions with float atomicAdd (E:868-869 into
+// gx[src], E:772-786 into grad_W).  On gfx950 float atomics run at ≈1.3 TB/s chip-wide against
+// ≈6 TB/s for plain stores, so the backward instead STORES every edge's message row once into its
+// slot of a source-sorted scratch array and a second pass sums each source's contiguous slots
+// (cdna_hip_programming.md Appendix B "Scatter / gather": store pass + per-destination sum pass).
+//   pos[e]      = slot of CSR edge e in (src, e)-sorted order   (stable radix sort: fixed order
+//                 inside every source's list => bitwise reproducible sums)
+//   src_ptr[s]  = first slot of table row s, src_ptr[n_table] = E
+#include "gat_internal.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace gat {
+namespace {
+
+__global__ __launch_bounds__(256) void iota_kernel(int32_t* v, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] = (int32_t)i;
+}
+__global__ __launch_bounds__(256) void invert_perm_kernel(const int32_t* __restrict__ perm, int32_t* __restrict__ pos,
+                                                         int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) pos[perm[i]] = (int32_t)i;
+}
+// src_ptr[s] = lower_bound(sorted_keys, s)
+__global__ __launch_bounds__(256) void segment_offsets_kernel(const int32_t* __restrict__ keys, int64_t n_keys,
+                                                             int32_t* __restrict__ ptr, int64_t n_seg) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s <= n_seg; s += stride) {
+        int64_t lo = 0, hi = n_keys;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)keys[mid] < s) lo = mid + 1; else hi = mid;
+        }
+        ptr[s] = (int32_t)lo;
+    }
+}
+
+// gPL[s][:] = sum over slots of s.  Row = HD floats read as float4 by HD/4 lanes, 64/(HD/4) rows
+// per wave-instruction (1 KiB), U instructions in flight.
+template <int HD>
+__global__ __launch_bounds__(256) void gpl_sum_kernel(const int32_t* __restrict__ src_ptr,
+                                                      const float* __restrict__ msg, float* __restrict__ gPL,
+                                                      int64_t n_table) {
+    constexpr int LPR = HD / 4;          // lanes per row
+    constexpr int RPI = 64 / LPR;        // rows per wave-instruction
+    constexpr int U = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+    if (s >= n_table) return;
+    const int b = src_ptr[s], e = src_ptr[s + 1];
+    const int q = lane % LPR, r = lane / LPR;
+    const float4* m4 = reinterpret_cast<const float4*>(msg);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = b; i0 < e; i0 += RPI * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * RPI + r;
+            v[u] = (i < e) ? m4[(int64_t)i * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+        acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+    }
+    if (r == 0) reinterpret_cast<float4*>(gPL)[s * LPR + q] = acc;
+}
+
+}  // namespace
+
+int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t* pos, int32_t* src_ptr,
+              hipStream_t s) {
+    if (n_edges <= 0) {
+        GAT_HIP(hipMemsetAsync(src_ptr, 0, (size_t)(n_table + 1) * sizeof(int32_t), s));
+        return 0;
+    }
+    int32_t *iota = nullptr, *keys_out = nullptr, *perm = nullptr;
+    void* temp = nullptr;
+    size_t temp_bytes = 0;
+    int end_bit = 1;
+    while (((int64_t)1 << end_bit) < n_table) ++end_bit;
+    int rc = 0;
+    auto cleanup = [&]() { (void)hipFree(iota); (void)hipFree(keys_out); (void)hipFree(perm); (void)hipFree(temp); };
+#define CSC_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { cleanup(); return fail((int)e__, std::string(#x) + ": " + hipGetErrorString(e__)); } } while (0)
+    CSC_HIP(hipMalloc((void**)&iota, n_edges * sizeof(int32_t)));
+    CSC_HIP(hipMalloc((void**)&keys_out, n_edges * sizeof(int32_t)));
+    CSC_HIP(hipMalloc((void**)&perm, n_edges * sizeof(int32_t)));
+    int64_t blocks = std::min<int64_t>((n_edges + 255) / 256, 65536);
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)blocks), dim3(256), 0, s, iota, n_edges);
+    CSC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, col_idx, keys_out, iota, perm, (int)n_edges, 0,
+                                               end_bit, s));
+    CSC_HIP(hipMalloc(&temp, temp_bytes));
+    CSC_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, col_idx, keys_out, iota, perm, (int)n_edges, 0,
+                                               end_bit, s));
+    hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, perm, pos, n_edges);
+    const int64_t sblocks = std::min<int64_t>((n_table + 1 + 255) / 256, 65536);
+    hipLaunchKernelGGL(segment_offsets_kernel, dim3((unsigned)sblocks), dim3(256), 0, s, keys_out, n_edges, src_ptr,
+                       n_table);
+    CSC_HIP(hipGetLastError());
+    CSC_HIP(hipStreamSynchronize(s));
+#undef CSC_HIP
+    cleanup();
+    return rc;
+}
+
+int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int32_t HD,
+                   hipStream_t s) {
+    if (n_table <= 0) return 0;
+    const dim3 grid((unsigned)((n_table + 3) / 4)), block(256);
+    switch (HD) {
+        case 64: hipLaunchKernelGGL(gpl_sum_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+        case 32: hipLaunchKernelGGL(gpl_sum_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+        case 16: hipLaunchKernelGGL(gpl_sum_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+        case 8: hipLaunchKernelGGL(gpl_sum_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+        default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
+    }
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gat

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
 //   gs     = ge a LReLU'(s)                             (E:774-775)
 //   grad_a += ge LReLU(s)   gPR[dst] += gs   gPL[src] += g alpha + gs   (E:769-782, 859-869)
 // ------------------------------------------------------------------------------------------------
-template <int HD, int D>
+template <int HD, int D, bool STORE>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
     constexpr int G = 64 / HD;
     constexpr int U = 16 / G;
@@ -214,14 +214,15 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
         float gpr = 0.f;
         for (int e0 = b; e0 < e_end; e0 += CH) {
             float v[U], al[U];
-            int sid[U];
+            int sid[U];     // gPL row (atomics path) or message slot (store path)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int j = e0 + u * G + gidx;
                 const bool valid = j < e_end;
-                sid[u] = valid ? A.col_idx[j] : 0;
-                v[u] = valid ? A.PL[(int64_t)sid[u] * HD + c] : 0.f;
+                const int src = valid ? A.col_idx[j] : 0;
+                v[u] = valid ? A.PL[(int64_t)src * HD + c] : 0.f;
                 al[u] = valid ? A.alpha[(int64_t)j * H + c / D] : 0.f;
+                if constexpr (STORE) sid[u] = valid ? A.pos[j] : 0; else sid[u] = src;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -234,7 +235,9 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
                 ga = fmaf(ge, pos ? s : s * slope, ga);
                 gpr += gs;
                 if (j < e_end) {
-                    unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, fmaf(g, al[u], gs));
+                    const float msg = fmaf(g, al[u], gs);          // d/dPL[src] from this edge
+                    if constexpr (STORE) A.msg[(int64_t)sid[u] * HD + c] = msg;
+                    else unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, msg);
                     if (A.ge != nullptr && (c % D) == 0) A.ge[(int64_t)j * H + c / D] = ge;
                 }
             }
@@ -381,7 +384,10 @@ int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
 }
 template <int HD, int D>
 int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((edge_bwd_kernel<HD, D>), dim3((unsigned)a.ga_blocks), dim3(256), 0, s, a);
+    if (a.pos != nullptr && a.msg != nullptr)
+        hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true>), dim3((unsigned)a.ga_blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false>), dim3((unsigned)a.ga_blocks), dim3(256), 0, s, a);
     GAT_HIP(hipGetLastError());
     return 0;
 }
@@ -424,10 +430,25 @@ int edge_backward_blocks(int64_t n_rows) {
     return (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
 }
 
+static int fast_probe(const int&, hipStream_t) { return 1; }
+template <int HD, int D>
+int fast_probe_t(const int& x, hipStream_t s) { return fast_probe(x, s); }
+
+bool edge_fast_path(int32_t H, int32_t D_) {
+    const int HD = H * D_, D = D_;
+    const int dummy = 0;
+    auto probe = [&]() -> int {
+        GAT_DISPATCH_HD_D(fast_probe_t, dummy, nullptr)
+        return 0;
+    };
+    return probe() == 1;
+}
+
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s) {
     const int HD = a.H * a.D, D = a.D;
     if (a.ga_blocks != edge_backward_blocks(a.n_rows)) return fail(GAT_E_INVALID, "edge_backward: ga_blocks mismatch");
     GAT_DISPATCH_HD_D(run_bwd, a, s)
+    if (a.pos != nullptr) return fail(GAT_E_INVALID, "edge_backward: the generic path has no store mode");
     const size_t lds = (size_t)(3 * a.H + 2 * HD) * sizeof(float);
     if (lds > 64 * 1024) return fail(GAT_E_UNSUPPORTED, "edge_backward: H*D too large for the generic path");
     hipLaunchKernelGGL(edge_bwd_generic, dim3((unsigned)a.ga_blocks), dim3(64), lds, s, a);

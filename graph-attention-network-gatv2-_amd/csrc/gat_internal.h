@@ -57,7 +57,9 @@ struct EdgeBwdArgs {
     const float* alpha;       // [E][H]
     const float* hpre;        // [n_rows][HD]
     const float* g;           // [n_rows][HD]  dL/dh_pre
-    float* gPL;               // [n_table][HD]  zeroed by the caller, added into
+    float* gPL;               // [n_table][HD]  atomics path only: zeroed by the caller, added into
+    const int32_t* pos;       // [E] CSC slot of every edge, or null = atomics path
+    float* msg;               // [E][HD] message rows by slot (store path; summed by launch_gpl_sum)
     float* gPR;               // [n_rows][HD]   written
     float* ge;                // [E][H] or null (tap)
     float* ga_partial;        // [ga_blocks][HD] written
@@ -68,6 +70,13 @@ struct EdgeBwdArgs {
 };
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s);
 int edge_backward_blocks(int64_t n_rows);   // grid size used by launch_edge_backward
+bool edge_fast_path(int32_t H, int32_t D);  // wave-per-row templates cover this (H, D)
+
+// ---- source-major slot index + segmented sum (gat_csc.hip) ----------------------------------------
+int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t* pos, int32_t* src_ptr,
+              hipStream_t s);
+int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int32_t HD,
+                   hipStream_t s);
 
 int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);
