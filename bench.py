@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0 = auto (~15 s of CPU work)")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--beta", type=float, default=0.75, help="power-law exponent of the degree law (debug)")
     return ap.parse_args()
 
 
@@ -102,7 +103,7 @@ def main():
 
     # ---- synthetic inputs (same on every rank; each keeps its destination range) ----
     t_gen = time.perf_counter()
-    row_ptr, col_idx = pkg.synth.powerlaw_graph(n, e)
+    row_ptr, col_idx = pkg.synth.powerlaw_graph(n, e, beta=args.beta)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         ctx = pkg.GatContext(heads, outdims, f, c, device=local_rank, stream=stream.cuda_stream, collect_timing=True)

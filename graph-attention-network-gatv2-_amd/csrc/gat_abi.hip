@@ -36,6 +36,30 @@ struct Layer {
 
 struct Pending { int k; hipEvent_t e0, e1; };
 
+void build_worklist(const int32_t* rp, int64_t n_rows, WorkList& w) {
+    w.items.clear(); w.slot_info.clear(); w.n_slots = 0;
+    // pass 1: segments of split rows first (the longest items start earliest)
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int32_t b = rp[r], e = rp[r + 1];
+        if (e - b <= kSegEdges) continue;
+        const int32_t nseg = (e - b + kSegEdges - 1) / kSegEdges, first = w.n_slots;
+        for (int32_t sgm = 0; sgm < nseg; ++sgm) {
+            const int32_t sb = b + sgm * kSegEdges, se = std::min(e, sb + kSegEdges);
+            const int32_t item = (int32_t)(w.items.size() / 4);
+            w.items.insert(w.items.end(), {(int32_t)r, sb, se, w.n_slots});
+            w.slot_info.insert(w.slot_info.end(), {(int32_t)r, first, nseg, item});
+            ++w.n_slots;
+        }
+    }
+    // pass 2: every other row is one item
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int32_t b = rp[r], e = rp[r + 1];
+        if (e - b > kSegEdges) continue;
+        w.items.insert(w.items.end(), {(int32_t)r, b, e, -1});
+    }
+    w.n_items = (int64_t)(w.items.size() / 4);
+}
+
 }  // namespace gat
 
 struct gat_ctx {
@@ -58,6 +82,9 @@ struct gat_ctx {
     int32_t* csc_pos = nullptr;                     // [E] slot of each CSR edge in source-major order
     int32_t* csc_ptr = nullptr;                     // [n_table+1]
     float* msg = nullptr; int32_t msg_hd = 0;       // [E][msg_hd] per-edge message rows (store path)
+    gat::WorkList work;                             // host copy of the item list
+    int4* items = nullptr; int4* slot_info = nullptr;
+    float* part_acc = nullptr; float* part_mz = nullptr;
     float* ga_partial = nullptr; int32_t ga_blocks = 0;
     float* gw_scratch = nullptr;
     float* hb_partial = nullptr;
@@ -162,6 +189,18 @@ static int ensure_buffers(gat_ctx* c) {
     }
     if (!c->gPL_bound) GAT_TRY(dalloc(c, &c->gPL, T * c->HDmax));
     GAT_TRY(dalloc(c, &c->gPR, N * c->HDmax));
+    // work items (rows / hub-row segments) of the wave-per-item kernels
+    GAT_TRY(dalloc(c, &c->items, std::max<int64_t>(c->work.n_items, 1)));
+    GAT_TRY(dalloc(c, &c->slot_info, std::max<int32_t>(c->work.n_slots, 1)));
+    GAT_TRY(dalloc(c, &c->part_acc, (int64_t)std::max<int32_t>(c->work.n_slots, 1) * c->HDmax));
+    GAT_TRY(dalloc(c, &c->part_mz, (int64_t)std::max<int32_t>(c->work.n_slots, 1) * 2 * c->Hmax));
+    if (c->work.n_items > 0)
+        GAT_HIP(hipMemcpyAsync(c->items, c->work.items.data(), c->work.items.size() * sizeof(int32_t),
+                               hipMemcpyHostToDevice, c->stream));
+    if (c->work.n_slots > 0)
+        GAT_HIP(hipMemcpyAsync(c->slot_info, c->work.slot_info.data(), c->work.slot_info.size() * sizeof(int32_t),
+                               hipMemcpyHostToDevice, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
     // Store-then-sum backward for the layers on the wave-per-row fast path: needs the source-major
     // slot index and an [E][H*D] scratch.  GAT_BWD_ATOMICS=1 forces the float-atomic variant (A/B).
     int32_t msg_hd = 0;
@@ -306,6 +345,13 @@ static int set_graph_common(gat_ctx* c, const int32_t* row_ptr, const int32_t* c
     GAT_HIP(hipMemcpyAsync(c->row_ptr, row_ptr, (n_rows + 1) * sizeof(int32_t), kind, c->stream));
     if (n_edges > 0) GAT_HIP(hipMemcpyAsync(c->col_idx, col_idx, n_edges * sizeof(int32_t), kind, c->stream));
     GAT_HIP(hipStreamSynchronize(c->stream));
+    if (kind == hipMemcpyHostToDevice) {
+        build_worklist(row_ptr, n_rows, c->work);
+    } else {
+        std::vector<int32_t> h(n_rows + 1);
+        GAT_HIP(hipMemcpy(h.data(), c->row_ptr, (n_rows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+        build_worklist(h.data(), n_rows, c->work);
+    }
     c->have_graph = true;
     return ensure_buffers(c);
 }
@@ -450,6 +496,8 @@ int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
     a.alpha = y.alpha; a.hpre = y.hpre; a.hout = y.hout; a.mstat = y.mstat; a.zstat = y.zstat;
     a.n_rows = c->n_rows; a.H = y.H; a.D = y.D; a.is_last = (l == c->cfg.num_layers - 1);
     a.slope = c->cfg.negative_slope;
+    a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
+    a.part_acc = c->part_acc; a.part_mz = c->part_mz;
     Scope t(c, GAT_K_EDGE_FWD);
     return launch_edge_forward(a, c->stream);
 }
@@ -500,6 +548,8 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
     a.alpha = y.alpha; a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge;
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
+    a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
+    a.part_acc = c->part_acc;
     a.ga_partial = c->ga_partial; a.ga_blocks = c->ga_blocks; a.n_rows = c->n_rows; a.H = y.H; a.D = y.D;
     a.slope = c->cfg.negative_slope;
     {
@@ -679,6 +729,25 @@ struct TmpBufs {
         p.push_back(q); *out = (float*)q;
         return 0;
     }
+    // device work list for caller-provided CSR (op-level entry points have no context)
+    WorkList w;
+    int4* items = nullptr; int4* slot_info = nullptr; float* part_acc = nullptr; float* part_mz = nullptr;
+    int worklist(const int32_t* d_row_ptr, int64_t n, int32_t hd, int32_t h, hipStream_t s) {
+        std::vector<int32_t> rp(n + 1);
+        GAT_HIP(hipMemcpyAsync(rp.data(), d_row_ptr, (n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        build_worklist(rp.data(), n, w);
+        float *fi, *fs;
+        GAT_TRY(get(&fi, std::max<int64_t>(w.n_items, 1) * 4));
+        GAT_TRY(get(&fs, std::max<int64_t>(w.n_slots, 1) * 4));
+        GAT_TRY(get(&part_acc, (int64_t)std::max<int32_t>(w.n_slots, 1) * hd));
+        GAT_TRY(get(&part_mz, (int64_t)std::max<int32_t>(w.n_slots, 1) * 2 * h));
+        items = (int4*)fi; slot_info = (int4*)fs;
+        if (w.n_items) GAT_HIP(hipMemcpyAsync(items, w.items.data(), w.items.size() * 4, hipMemcpyHostToDevice, s));
+        if (w.n_slots) GAT_HIP(hipMemcpyAsync(slot_info, w.slot_info.data(), w.slot_info.size() * 4, hipMemcpyHostToDevice, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
 };
 
 int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, const float* d_x, const float* d_w,
@@ -694,6 +763,9 @@ int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, con
     EdgeFwdArgs a{};
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
     a.hpre = d_hpre; a.hout = d_hout; a.n_rows = n; a.H = h; a.D = d; a.is_last = is_last; a.slope = slope;
+    GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
+    a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots;
+    a.part_acc = t.part_acc; a.part_mz = t.part_mz;
     GAT_TRY(launch_edge_forward(a, s));
     GAT_TRY(launch_transpose_eh_to_he(alpha, d_attn_coeff, e, h, s));
     GAT_HIP(hipStreamSynchronize(s));
@@ -721,6 +793,9 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
     a.hpre = d_hpre; a.g = d_g; a.gPL = gPL; a.gPR = gPR; a.ge = nullptr; a.ga_partial = gap; a.ga_blocks = blocks;
     a.n_rows = n; a.H = h; a.D = d; a.slope = slope;
+    GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
+    a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots;
+    a.part_acc = t.part_acc;
     GAT_TRY(launch_edge_backward(a, s));
     GAT_TRY(launch_reduce_partials_add(gap, blocks, HD, d_grad_a, s));
     GAT_TRY(launch_grad_w(gPL, gPR, d_x, d_grad_w, scr, n, f, HD, s));

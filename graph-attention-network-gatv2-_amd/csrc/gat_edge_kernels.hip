@@ -8,20 +8,26 @@
 //   a1 CSR->COO E:67-84
 // with ONE destination-segmented pass per direction over projected features
 //   PL = X·W_left^T, PR = X·W_right^T   (s[e,h,k] = PL[src,h,k] + PR[dst,h,k]).
-// A wave owns a CSR row: every neighbour row PL[src] is one coalesced H*D-float read, the
-// per-head reductions are DPP/shuffle all-reduces, the softmax is online (single gather of
-// PL[src] per edge), h_pre is written once without atomics, and the softmax backward uses
-//   sum_k galpha_k alpha_k == <g[dst,h,:], h_pre[dst,h,:]>
-// which makes it O(E) and single-pass.
+// A wave owns a work item = a CSR row, or a <=128-edge segment of a long row (power-law hubs
+// are split so that no wave runs longer than ~8 chunks).  Every neighbour row PL[src] is one
+// coalesced H*D-float read, the per-head reductions are DPP/shuffle all-reduces, the softmax is
+// online (single gather of PL[src] per edge), h_pre is written once without atomics, and the
+// softmax backward uses   sum_k galpha_k alpha_k == <g[dst,h,:], h_pre[dst,h,:]>
+// which makes it O(E) and single-pass.  Split rows are finished by small fix-up kernels that
+// merge the per-segment partials.
 //
 // HBM layouts: PL/PR/h_pre/g [rows][H*D] f32; alpha, ge [E][H] f32 (edge-major: the H values
-// of an edge are one 4H-byte segment); CSR int32.
+// of an edge are one 4H-byte segment); CSR int32; work items int4 {row, beg, end, slot|-1}.
 #include "gat_internal.h"
 
 namespace gat {
 namespace {
 
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -68,111 +74,24 @@ __global__ __launch_bounds__(256) void csr_to_coo_kernel(const int32_t* __restri
 
 // ------------------------------------------------------------------------------------------------
 // Forward edge pass, fast path: H*D in {8,16,32,64}, D a power of two.
-// One wave per destination row.  G = 64/HD edges are gathered per wave-instruction (lane ->
-// (group, channel)); U gathers per group are issued back to back before any is consumed.
+// G = 64/HD edges are gathered per wave-instruction (lane -> (group, channel)); U gathers per
+// group are issued back to back before any is consumed.  Scores are kept in the log2 domain
+// (a pre-scaled by log2 e) so that every softmax term is one v_exp_f32.
 // ------------------------------------------------------------------------------------------------
 template <int HD, int D>
-__global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
-    constexpr int G = 64 / HD;      // edges per wave-instruction
-    constexpr int U = 16 / G;       // gathers in flight per group
-    constexpr int CH = 16;          // edges per chunk (= U*G)
+__device__ __forceinline__ void fwd_write_row(const EdgeFwdArgs& A, int64_t row, int lane, float m2, float Z,
+                                              float acc) {
     constexpr int H = HD / D;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
-    if (row >= A.n_rows) return;
     const int c = lane % HD, gidx = lane / HD;
-    const int b = A.row_ptr[row], e_end = A.row_ptr[row + 1];
-    const float pr = A.PR[row * HD + c];
-    const float ac = A.a[c];
-    const float slope = A.slope;
-    float m = -1e9f, Z = 0.f, acc = 0.f;     // E:336 seeds the max with -1e9f
-    const bool multi = (e_end - b) > CH;
-    float sc[U];
-
-    for (int e0 = b; e0 < e_end || e0 == b; e0 += CH) {
-        float v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = e0 + u * G + gidx;
-            const bool valid = j < e_end;
-            const int sid = valid ? A.col_idx[j] : 0;
-            v[u] = valid ? A.PL[(int64_t)sid * HD + c] : 0.f;
-        }
-        float cm = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = e0 + u * G + gidx;
-            const float t = group_sum<D>(ac * lrelu(v[u] + pr, slope));
-            sc[u] = (j < e_end) ? t : -INFINITY;
-            cm = fmaxf(cm, sc[u]);
-        }
-        const float mn = fmaxf(m, cm);
-        const float scale = __expf(m - mn);
-        Z *= scale;
-        acc *= scale;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float p = __expf(sc[u] - mn);      // 0 for padded edges
-            Z += p;
-            acc = fmaf(p, v[u], acc);
-        }
-        m = mn;
-        if (multi) {                                 // park raw scores; normalised after the loop
-            if ((c % D) == 0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int j = e0 + u * G + gidx;
-                    if (j < e_end) A.alpha[(int64_t)j * H + c / D] = sc[u];
-                }
-            }
-        }
-        if (e0 + CH >= e_end) break;
-    }
-
-    // merge the G edge groups (online-softmax combine); afterwards all groups agree
-#pragma unroll
-    for (int off = HD; off < 64; off <<= 1) {
-        const float mo = __shfl_xor(m, off), Zo = __shfl_xor(Z, off), ao = __shfl_xor(acc, off);
-        const float mn = fmaxf(m, mo);
-        const float s1 = __expf(m - mn), s2 = __expf(mo - mn);
-        Z = Z * s1 + Zo * s2;
-        acc = acc * s1 + ao * s2;
-        m = mn;
-    }
-    const float denom = Z + 1e-8f;                   // E:379
-    const float hp = acc * (1.0f / denom);
-
-    if (!multi) {                                    // whole row still in registers
-        if ((c % D) == 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = b + u * G + gidx;
-                if (j < e_end) A.alpha[(int64_t)j * H + c / D] = __expf(sc[u] - m) / denom;
-            }
-        }
-    } else {
-        // The raw scores were written by other lanes of this wave: drain the stores, then
-        // sweep the row's [deg][H] slice (contiguous) and normalise in place.
-        __threadfence_block();
-        const int total = (e_end - b) * H;
-        float* arow = A.alpha + (int64_t)b * H;
-        for (int i0 = 0; i0 < total; i0 += 64) {
-            const int i = i0 + lane;
-            const int h = i % H;
-            const float mh = __shfl(m, h * D), dh = __shfl(denom, h * D);
-            if (i < total) arow[i] = __expf(arow[i] - mh) / dh;
-        }
-    }
-
+    const float hp = acc * (1.0f / (Z + 1e-8f));     // E:379 epsilon
     if (gidx == 0) {
         A.hpre[row * HD + c] = hp;
         if ((c % D) == 0 && A.mstat != nullptr) {
-            A.mstat[row * H + c / D] = m;
+            A.mstat[row * H + c / D] = fmaxf(m2 * kLn2, -1e9f);
             A.zstat[row * H + c / D] = Z;
         }
     }
-    const float act = lrelu(hp, slope);
+    const float act = lrelu(hp, A.slope);
     if (!A.is_last) {
         if (gidx == 0) A.hout[row * HD + c] = act;   // concat heads (E:452-457)
     } else {
@@ -183,68 +102,253 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
     }
 }
 
+// alpha[b..e_end) holds raw log2-domain scores: normalise in place (contiguous [deg][H] slice).
+template <int HD, int D>
+__device__ __forceinline__ void fwd_normalize_slice(const EdgeFwdArgs& A, int b, int e_end, int lane, float m2,
+                                                    float denom) {
+    constexpr int H = HD / D;
+    const int total = (e_end - b) * H;
+    float* arow = A.alpha + (int64_t)b * H;
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const int i = i0 + lane;
+        const int h = i % H;
+        const float mh = __shfl(m2, h * D), dh = __shfl(denom, h * D);
+        if (i < total) arow[i] = exp2_fast(arow[i] - mh) / dh;
+    }
+}
+
+// A value the compiler must treat as per-lane: predicates built from it become EXEC masks instead
+// of scalar branches, which keeps the chunk bodies below straight-line code (hipcc drains
+// vmcnt(0) at every join point of a scalar branch that has memory operations behind it).
+__device__ __forceinline__ int per_lane(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// One chunk of UU slots per edge group: UU independent gathers issued back to back (indices
+// clamped into the item, so loads need no predicate), then scores, then the online-softmax update.
+template <int HD, int D, int UU, int USC>
+__device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_end, int e_end_v, int c, int gidx,
+                                          float pr, float ac2, bool multi, float (&sc)[USC], float& m, float& Z,
+                                          float& acc) {
+    constexpr int G = 64 / HD;
+    constexpr int H = HD / D;
+    float v[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const int j = e0 + u * G + gidx;
+        const int jc = j < e_end ? j : e_end - 1;
+        const int sid = A.col_idx[jc];
+        v[u] = A.PL[(int64_t)sid * HD + c];
+    }
+    float cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const int j = e0 + u * G + gidx;
+        const float t = group_sum<D>(ac2 * lrelu(v[u] + pr, A.slope));
+        sc[u] = (j < e_end_v) ? t : -INFINITY;
+        cm = fmaxf(cm, sc[u]);
+    }
+    const float mn = fmaxf(m, cm);
+    const float scale = exp2_fast(m - mn);
+    Z *= scale;
+    acc *= scale;
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const float p = exp2_fast(sc[u] - mn);       // 0 for padded slots
+        Z += p;
+        acc = fmaf(p, v[u], acc);
+    }
+    m = mn;
+    if (multi) {                                     // park raw scores; normalised later
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            const int j = e0 + u * G + gidx;
+            if ((c % D) == 0 && j < e_end_v) A.alpha[(int64_t)j * H + c / D] = sc[u];
+        }
+    }
+}
+
+template <int HD, int D>
+__global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
+    constexpr int G = 64 / HD;      // edges per wave-instruction
+    constexpr int U = 16 / G;       // gathers in flight per group
+    constexpr int CH = 16;          // edges per chunk (= U*G)
+    constexpr int H = HD / D;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t it = (int64_t)blockIdx.x * 4 + wave;
+    if (it >= A.n_items) return;
+    const int4 item = A.items[it];
+    const int64_t row = item.x;
+    const int b = item.y, e_end = item.z, slot = item.w;
+    const int e_end_v = per_lane(e_end);
+    const bool split = slot >= 0;                    // one segment of a long row
+    const int c = lane % HD, gidx = lane / HD;
+    const float pr = A.PR[row * HD + c];
+    const float ac2 = A.a[c] * kLog2e;
+    float m = -1e9f * kLog2e, Z = 0.f, acc = 0.f;    // E:336 seeds the max with -1e9f
+    const bool multi = split || (e_end - b) > CH;
+    float sc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sc[u] = -INFINITY;
+
+    for (int e0 = b; e0 < e_end; e0 += CH) {
+        if constexpr (U >= 2) {
+            if (e_end - e0 <= CH / 2) fwd_chunk<HD, D, U / 2, U>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
+            else fwd_chunk<HD, D, U, U>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
+        } else {
+            fwd_chunk<HD, D, U, U>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
+        }
+    }
+
+    // merge the G edge groups (online-softmax combine); afterwards all groups agree
+#pragma unroll
+    for (int off = HD; off < 64; off <<= 1) {
+        const float mo = __shfl_xor(m, off), Zo = __shfl_xor(Z, off), ao = __shfl_xor(acc, off);
+        const float mn = fmaxf(m, mo);
+        const float s1 = exp2_fast(m - mn), s2 = exp2_fast(mo - mn);
+        Z = Z * s1 + Zo * s2;
+        acc = acc * s1 + ao * s2;
+        m = mn;
+    }
+
+    if (split) {                                     // partial (m, Z, acc) of this segment
+        if (gidx == 0) {
+            A.part_acc[(int64_t)slot * HD + c] = acc;
+            if ((c % D) == 0) {
+                A.part_mz[(int64_t)slot * 2 * H + c / D] = m;
+                A.part_mz[(int64_t)slot * 2 * H + H + c / D] = Z;
+            }
+        }
+        return;
+    }
+    const float denom = Z + 1e-8f;
+    if (!multi) {                                    // whole row still in registers
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = b + u * G + gidx;
+            if ((c % D) == 0 && j < e_end_v) A.alpha[(int64_t)j * H + c / D] = exp2_fast(sc[u] - m) / denom;
+        }
+    } else {
+        // raw scores were written by other lanes of this wave: drain the stores, then sweep
+        __threadfence_block();
+        fwd_normalize_slice<HD, D>(A, b, e_end, lane, m, denom);
+    }
+    fwd_write_row<HD, D>(A, row, lane, m, Z, acc);
+}
+
+// Split rows: one wave per segment merges ALL partials of its row (L2-hot, <= a few hundred
+// bytes each), normalises its own alpha slice, and the row's first segment writes the outputs.
+template <int HD, int D>
+__global__ __launch_bounds__(256) void edge_fwd_fix_kernel(EdgeFwdArgs A) {
+    constexpr int H = HD / D;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= A.n_slots) return;
+    const int4 info = A.slot_info[slot];             // {row, first_slot, nseg, item}
+    const int4 item = A.items[info.w];
+    const int c = lane % HD;
+    float m = -1e9f * kLog2e, Z = 0.f, acc = 0.f;
+    for (int s = info.y; s < info.y + info.z; ++s) {
+        const float ms = A.part_mz[(int64_t)s * 2 * H + c / D];
+        const float Zs = A.part_mz[(int64_t)s * 2 * H + H + c / D];
+        const float as = A.part_acc[(int64_t)s * HD + c];
+        const float mn = fmaxf(m, ms);
+        const float s1 = exp2_fast(m - mn), s2 = exp2_fast(ms - mn);
+        Z = Z * s1 + Zs * s2;
+        acc = acc * s1 + as * s2;
+        m = mn;
+    }
+    fwd_normalize_slice<HD, D>(A, item.y, item.z, lane, m, Z + 1e-8f);
+    if (slot == info.y) fwd_write_row<HD, D>(A, info.x, lane, m, Z, acc);
+}
+
 // ------------------------------------------------------------------------------------------------
-// Backward edge pass, fast path.  Grid-stride over rows (fixed grid so that the per-block
-// grad_a partials stay small).  Per edge: one PL[src] gather, one alpha read, one gPL row add.
+// Backward edge pass, fast path.  Fixed grid, work items dealt round-robin (all items are <= 128
+// edges, so the static deal is balanced) — fixed so that the per-block grad_a partials stay small.
+// Per edge: one PL[src] gather, one alpha read, one message row out.
 //   galpha = <g[dst,h,:], PL[src,h,:]>                 (E:632-646)
 //   ge     = alpha (galpha - <g[dst,h,:], h_pre[dst,h,:]>)   (≡ E:682-693)
 //   gs     = ge a LReLU'(s)                             (E:774-775)
 //   grad_a += ge LReLU(s)   gPR[dst] += gs   gPL[src] += g alpha + gs   (E:769-782, 859-869)
+// STORE: message row -> its CSC slot (summed per source by gpl_sum_kernel); else float atomics.
 // ------------------------------------------------------------------------------------------------
-template <int HD, int D, bool STORE>
+template <int HD, int D, int UU, bool STORE, bool TAPS>
+__device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_end, int e_end_v, int c, int gidx,
+                                          float g, float pr, float dot, float ac, float& ga, float& gpr) {
+    constexpr int G = 64 / HD;
+    constexpr int H = HD / D;
+    float v[UU], al[UU];
+    int sid[UU];            // gPL row (atomics path) or message slot (store path)
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const int j = e0 + u * G + gidx;
+        const int jc = j < e_end ? j : e_end - 1;                // clamped: loads need no predicate
+        const int src = A.col_idx[jc];
+        v[u] = A.PL[(int64_t)src * HD + c];
+        al[u] = A.alpha[(int64_t)jc * H + c / D];
+        if constexpr (STORE) sid[u] = A.pos[jc]; else sid[u] = src;
+    }
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const int j = e0 + u * G + gidx;
+        const bool valid = j < e_end_v;
+        const float galpha = group_sum<D>(g * v[u]);
+        const float ge = valid ? al[u] * (galpha - dot) : 0.f;   // padded slots contribute nothing
+        const float s = v[u] + pr;
+        const bool pos = s > 0.f;
+        const float gs = ge * ac * (pos ? 1.0f : A.slope);
+        ga = fmaf(ge, pos ? s : s * A.slope, ga);
+        gpr += gs;
+        const float msg = fmaf(g, al[u], gs);                    // d/dPL[src] from this edge
+        if (valid) {
+            if constexpr (STORE) A.msg[(int64_t)sid[u] * HD + c] = msg;
+            else unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, msg);
+        }
+        if constexpr (TAPS) {
+            if (valid && (c % D) == 0) A.ge[(int64_t)j * H + c / D] = ge;
+        }
+    }
+}
+
+template <int HD, int D, bool STORE, bool TAPS>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
     constexpr int G = 64 / HD;
     constexpr int U = 16 / G;
     constexpr int CH = 16;
-    constexpr int H = HD / D;
     __shared__ float red[4][HD];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane % HD, gidx = lane / HD;
     const float ac = A.a[c];
-    const float slope = A.slope;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     float ga = 0.f;
 
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < A.n_rows; row += nwaves) {
-        const int b = A.row_ptr[row], e_end = A.row_ptr[row + 1];
+    for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < A.n_items; it += nwaves) {
+        const int4 item = A.items[it];
+        const int64_t row = item.x;
+        const int b = item.y, e_end = item.z, slot = item.w;
+        const int e_end_v = per_lane(e_end);
         const float g = A.g[row * HD + c];
         const float pr = A.PR[row * HD + c];
         const float dot = group_sum<D>(g * A.hpre[row * HD + c]);
         float gpr = 0.f;
         for (int e0 = b; e0 < e_end; e0 += CH) {
-            float v[U], al[U];
-            int sid[U];     // gPL row (atomics path) or message slot (store path)
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = e0 + u * G + gidx;
-                const bool valid = j < e_end;
-                const int src = valid ? A.col_idx[j] : 0;
-                v[u] = valid ? A.PL[(int64_t)src * HD + c] : 0.f;
-                al[u] = valid ? A.alpha[(int64_t)j * H + c / D] : 0.f;
-                if constexpr (STORE) sid[u] = valid ? A.pos[j] : 0; else sid[u] = src;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int j = e0 + u * G + gidx;
-                const float galpha = group_sum<D>(g * v[u]);
-                const float ge = al[u] * (galpha - dot);        // 0 for padded edges (alpha = 0)
-                const float s = v[u] + pr;
-                const bool pos = s > 0.f;
-                const float gs = ge * ac * (pos ? 1.0f : slope);
-                ga = fmaf(ge, pos ? s : s * slope, ga);
-                gpr += gs;
-                if (j < e_end) {
-                    const float msg = fmaf(g, al[u], gs);          // d/dPL[src] from this edge
-                    if constexpr (STORE) A.msg[(int64_t)sid[u] * HD + c] = msg;
-                    else unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, msg);
-                    if (A.ge != nullptr && (c % D) == 0) A.ge[(int64_t)j * H + c / D] = ge;
-                }
+            if constexpr (U >= 2) {
+                if (e_end - e0 <= CH / 2) bwd_chunk<HD, D, U / 2, STORE, TAPS>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ga, gpr);
+                else bwd_chunk<HD, D, U, STORE, TAPS>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ga, gpr);
+            } else {
+                bwd_chunk<HD, D, U, STORE, TAPS>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ga, gpr);
             }
         }
 #pragma unroll
         for (int off = HD; off < 64; off <<= 1) gpr += __shfl_xor(gpr, off);
-        if (gidx == 0) A.gPR[row * HD + c] = gpr;
+        if (gidx == 0) {
+            if (slot < 0) A.gPR[row * HD + c] = gpr;
+            else A.part_acc[(int64_t)slot * HD + c] = gpr;      // segment partial, summed by the fix kernel
+        }
     }
 #pragma unroll
     for (int off = HD; off < 64; off <<= 1) ga += __shfl_xor(ga, off);
@@ -253,6 +357,21 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
     if (threadIdx.x < HD)
         A.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// gPR of split rows: sum of the row's segment partials in segment order (one thread per channel).
+__global__ __launch_bounds__(256) void edge_bwd_fix_kernel(const int4* __restrict__ slot_info, int32_t n_slots,
+                                                          const float* __restrict__ part, float* __restrict__ gPR,
+                                                          int32_t HD) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t slot = t / HD;
+    const int c = (int)(t % HD);
+    if (slot >= n_slots) return;
+    const int4 info = slot_info[slot];
+    if (slot != info.y) return;
+    float s = 0.f;
+    for (int k = info.y; k < info.y + info.z; ++k) s += part[(int64_t)k * HD + c];
+    gPR[(int64_t)info.x * HD + c] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,22 +492,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
-inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
-
 template <int HD, int D>
 int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
-    const int64_t blocks = (a.n_rows + 3) / 4;
+    if (a.items == nullptr) return fail(GAT_E_INVALID, "edge_forward: work-item list missing");
+    const int64_t blocks = (a.n_items + 3) / 4;
     hipLaunchKernelGGL((edge_fwd_kernel<HD, D>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     GAT_HIP(hipGetLastError());
+    if (a.n_slots > 0) {
+        hipLaunchKernelGGL((edge_fwd_fix_kernel<HD, D>), dim3((unsigned)((a.n_slots + 3) / 4)), dim3(256), 0, s, a);
+        GAT_HIP(hipGetLastError());
+    }
     return 0;
 }
 template <int HD, int D>
 int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
-    if (a.pos != nullptr && a.msg != nullptr)
-        hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true>), dim3((unsigned)a.ga_blocks), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false>), dim3((unsigned)a.ga_blocks), dim3(256), 0, s, a);
+    if (a.items == nullptr) return fail(GAT_E_INVALID, "edge_backward: work-item list missing");
+    const dim3 grid((unsigned)a.ga_blocks), block(256);
+    const bool store = a.pos != nullptr && a.msg != nullptr, taps = a.ge != nullptr;
+    if (store && taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, true>), grid, block, 0, s, a);
+    else if (store) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false>), grid, block, 0, s, a);
+    else if (taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, false>), grid, block, 0, s, a);
     GAT_HIP(hipGetLastError());
+    if (a.n_slots > 0) {
+        const int64_t threads = (int64_t)a.n_slots * HD;
+        hipLaunchKernelGGL(edge_bwd_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                           a.slot_info, a.n_slots, a.part_acc, a.gPR, HD);
+        GAT_HIP(hipGetLastError());
+    }
     return 0;
 }
 

@@ -45,7 +45,26 @@ struct EdgeFwdArgs {
     int32_t H, D;
     int32_t is_last;
     float slope;
+    // work items of the wave-per-item fast path (see WorkList); unused by the generic path
+    const int4* items;        // [n_items] {row, beg, end, slot|-1}
+    int64_t n_items;
+    const int4* slot_info;    // [n_slots] {row, first_slot, nseg, item}
+    int32_t n_slots;
+    float* part_acc;          // [n_slots][HD]  per-segment partial sums of split rows
+    float* part_mz;           // [n_slots][2H]  per-segment (max, sum)
 };
+
+// Work decomposition of a CSR graph for the wave-per-item kernels: every row with <= kSegEdges
+// in-edges is one item, longer rows (power-law hubs) are cut into segments of kSegEdges edges
+// (slot >= 0) that are listed first; slot_info describes the split rows for the fix-up kernels.
+constexpr int kSegEdges = 128;
+struct WorkList {
+    std::vector<int32_t> items;       // 4 per item
+    std::vector<int32_t> slot_info;   // 4 per slot
+    int64_t n_items = 0;
+    int32_t n_slots = 0;
+};
+void build_worklist(const int32_t* row_ptr, int64_t n_rows, WorkList& w);
 int launch_edge_forward(const EdgeFwdArgs& a, hipStream_t s);
 
 struct EdgeBwdArgs {
@@ -67,6 +86,11 @@ struct EdgeBwdArgs {
     int64_t n_rows;
     int32_t H, D;
     float slope;
+    const int4* items;        // as in EdgeFwdArgs
+    int64_t n_items;
+    const int4* slot_info;
+    int32_t n_slots;
+    float* part_acc;          // [n_slots][HD]  per-segment gPR partials of split rows
 };
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s);
 int edge_backward_blocks(int64_t n_rows);   // grid size used by launch_edge_backward
