@@ -1,0 +1,332 @@
+// gat_gemm_kernels.hip — the dense W_l / W_r feature projections of the GATv2 layer and their
+// backward, as exact-fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, so the
+// numerics are those of the reference's float loops up to summation order).
+//
+// The reference recomputes W·x inside every per-edge thread (E:303-316, 415-420, 636-640,
+// 752-761, 848-853).  Here it is computed once per node:
+//   project : [PL | PR] = X · [W_left ; W_right]^T                     (fwd of E:303-316)
+//   grad_x  : gX = gPL · W_left + gPR · W_right, fused with E:888-892  (E:859-869 summed over edges)
+//   grad_w  : gradW_left += gPL^T · X,  gradW_right += gPR^T · X       (E:770-782 summed over edges)
+// W stays in the reference layout [H*D][2F] (row j: cols 0..F-1 left, F..2F-1 right).
+//
+// Shapes are skinny: M = nodes (millions), K and N <= ~128.  project / grad_x therefore keep the
+// whole B operand resident in LDS for the lifetime of a persistent block and stream A straight
+// from HBM into MFMA fragments (one float4 per lane covers 4 k-steps: lane (i, half) reads
+// A[i][kb+4*half .. +3]; MFMA j' of the step pairs element j' with B row kb+4*half+j').  grad_w
+// reduces over the node dimension: node tiles are staged through double-buffered LDS in their
+// memory layout (which already is the k-major layout the fragments want), split-K over blocks,
+// slabs summed in fixed order.
+#include "gat_internal.h"
+
+namespace gat {
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// ---- A sources of the row-streaming kernel --------------------------------------------------------
+struct ASrcRows {                 // A(i,k) = X[i*ld + k]
+    const float* X; int32_t ld;
+    __device__ __forceinline__ float4 load4(int64_t i, int k) const {
+        return *reinterpret_cast<const float4*>(X + i * ld + k);
+    }
+    __device__ __forceinline__ float load1(int64_t i, int k) const { return X[i * ld + k]; }
+};
+struct ASrcGcat {                 // A(i,k) = k < HD ? gPL[i][k] : gPR[i][k-HD]
+    const float* gPL; const float* gPR; int32_t HD;
+    __device__ __forceinline__ float4 load4(int64_t i, int k) const {
+        return k < HD ? *reinterpret_cast<const float4*>(gPL + i * HD + k)
+                      : *reinterpret_cast<const float4*>(gPR + i * HD + (k - HD));
+    }
+    __device__ __forceinline__ float load1(int64_t i, int k) const {
+        return k < HD ? gPL[i * HD + k] : gPR[i * HD + (k - HD)];
+    }
+};
+// ---- B sources (copied to LDS once per block / K chunk) ----------------------------------------------
+struct BSrcProject {              // B(k=f, j): j < HD ? W[j][f] : W[j-HD][F+f]
+    const float* W; int32_t F, HD;
+    __device__ __forceinline__ float at(int k, int j) const {
+        return j < HD ? W[(int64_t)j * 2 * F + k] : W[(int64_t)(j - HD) * 2 * F + F + k];
+    }
+    static constexpr bool kAlongK = true;     // consecutive threads -> consecutive k (W rows are k-contiguous)
+};
+struct BSrcGradX {                // B(k=c, j=f): c < HD ? W[c][f] : W[c-HD][F+f]
+    const float* W; int32_t F, HD;
+    __device__ __forceinline__ float at(int k, int j) const {
+        return k < HD ? W[(int64_t)k * 2 * F + j] : W[(int64_t)(k - HD) * 2 * F + F + j];
+    }
+    static constexpr bool kAlongK = false;
+};
+// ---- epilogues ---------------------------------------------------------------------------------------
+struct EpiProject {               // cols < HD -> PL rows, else PR
+    float* PL; float* PR; int32_t HD;
+    __device__ __forceinline__ void operator()(int64_t i, int j, float v) const {
+        if (j < HD) PL[i * HD + j] = v; else PR[i * HD + (j - HD)] = v;
+    }
+};
+struct EpiGradX {                 // g_prev = gX ⊙ LReLU'(h_pre_prev)   (E:888-892)
+    float* out; const float* hpre_prev; int32_t ld; float slope;
+    __device__ __forceinline__ void operator()(int64_t i, int j, float v) const {
+        const float hv = hpre_prev[i * ld + j];
+        out[i * ld + j] = v * (hv > 0.f ? 1.0f : slope);
+    }
+};
+
+constexpr int kKC = 128;          // K chunk resident in LDS
+
+// C[M][N] = A[M][K] · B[K][N].  256 threads = 4 waves, each wave owns 32 rows x (NT*32) columns of a
+// 128-row tile; blocks are persistent over row tiles (grid.x) and column blocks of NT*32 (grid.y).
+template <int NT, bool VEC4, class AS, class BS, class EP>
+__global__ __launch_bounds__(256) void rowgemm_kernel(AS as, BS bs, EP ep, int64_t M, int32_t N, int32_t K,
+                                                      int32_t kc_lds) {
+    constexpr int NW = NT * 32;
+    extern __shared__ float Bsh[];                    // [kc_lds][NW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.y * NW;
+    const int64_t ntiles = (M + 127) / 128;
+    bool b_loaded = false;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row = tile * 128 + wave * 32 + li;
+        const bool rvalid = row < M;
+        v16f acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int k0 = 0; k0 < K; k0 += kKC) {
+            const int kc = (K - k0 < kKC) ? (K - k0) : kKC;
+            const int kc8 = (kc + 7) & ~7;
+            if (K > kKC || !b_loaded) {               // B chunk -> LDS (once per block when K <= kKC)
+                __syncthreads();
+                if constexpr (BS::kAlongK) {
+                    for (int idx = threadIdx.x; idx < kc8 * NW; idx += 256) {
+                        const int kk = idx % kc8, j = idx / kc8;
+                        Bsh[kk * NW + j] = (kk < kc && n0 + j < N) ? bs.at(k0 + kk, n0 + j) : 0.f;
+                    }
+                } else {
+                    for (int idx = threadIdx.x; idx < kc8 * NW; idx += 256) {
+                        const int kk = idx / NW, j = idx % NW;
+                        Bsh[kk * NW + j] = (kk < kc && n0 + j < N) ? bs.at(k0 + kk, n0 + j) : 0.f;
+                    }
+                }
+                b_loaded = true;
+                __syncthreads();
+            }
+            // all A fragments of this chunk in flight at once
+            float4 af[kKC / 8];
+#pragma unroll
+            for (int st = 0; st < kKC / 8; ++st) {
+                const int kk = st * 8 + 4 * half;
+                af[st] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (st * 8 < kc8) {
+                    if constexpr (VEC4) {
+                        if (rvalid && kk < kc) af[st] = as.load4(row, k0 + kk);
+                    } else {
+                        if (rvalid) {
+                            if (kk + 0 < kc) af[st].x = as.load1(row, k0 + kk + 0);
+                            if (kk + 1 < kc) af[st].y = as.load1(row, k0 + kk + 1);
+                            if (kk + 2 < kc) af[st].z = as.load1(row, k0 + kk + 2);
+                            if (kk + 3 < kc) af[st].w = as.load1(row, k0 + kk + 3);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < kKC / 8; ++st) {
+                if (st * 8 < kc8) {
+                    const float* brow = Bsh + (st * 8 + 4 * half) * NW + li;
+                    const float a4[4] = {af[st].x, af[st].y, af[st].z, af[st].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], brow[j * NW + nt * 32], acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int col = n0 + nt * 32 + li;
+                if (orow < M && col < N) ep(orow, col, acc[nt][r]);
+            }
+    }
+}
+
+template <class AS, class BS, class EP>
+int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, int32_t K, bool vec4, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int NT = N > 64 ? 4 : (N > 32 ? 2 : 1);
+    const int NW = NT * 32;
+    const int kc_lds = ((K < kKC ? K : kKC) + 7) & ~7;
+    const size_t lds = (size_t)kc_lds * NW * sizeof(float);
+    const int64_t ntiles = (M + 127) / 128;
+    int per_cu = (int)(160 * 1024 / (lds + 1024));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
+    const int64_t gx = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    const dim3 grid((unsigned)gx, (unsigned)((N + NW - 1) / NW));
+#define GAT_ROWGEMM(NT_, V_) hipLaunchKernelGGL((rowgemm_kernel<NT_, V_, AS, BS, EP>), grid, dim3(256), lds, s, as, bs, ep, M, N, K, kc_lds)
+    if (vec4) { if (NT == 4) GAT_ROWGEMM(4, true); else if (NT == 2) GAT_ROWGEMM(2, true); else GAT_ROWGEMM(1, true); }
+    else { if (NT == 4) GAT_ROWGEMM(4, false); else if (NT == 2) GAT_ROWGEMM(2, false); else GAT_ROWGEMM(1, false); }
+#undef GAT_ROWGEMM
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- grad_w: slabs[z][c][f] = sum over the block's nodes of [gPL|gPR][n][c] * X[n][f] ------------------
+// Block tile 128 (c) x 128 (f), 2x2 waves of 64x64; node tiles of 32 staged through two LDS buffers in
+// memory layout ([node][c] and [node][f] are already k-major); global loads of tile t+1 are in flight
+// while tile t is multiplied.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gPL, const float* __restrict__ gPR,
+                                                    const float* __restrict__ X, float* __restrict__ slabs,
+                                                    int64_t n_rows, int32_t HD, int32_t F, int64_t kchunk) {
+    constexpr int KT = 32, BM = 128, BN = 128;
+    __shared__ float As[2][KT][BM];
+    __shared__ float Bs[2][KT][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, half = lane >> 5;
+    const int M = 2 * HD;
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const int64_t kb = (int64_t)blockIdx.z * kchunk;
+    const int64_t ke = (kb + kchunk < n_rows) ? kb + kchunk : n_rows;
+    v16f acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[4], rb[4];              // staging registers: 4 float4 of A and of B per thread per tile
+    auto load_tile = [&](int64_t n0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = tid + 256 * p;
+            const int kk = idx >> 5, c = (idx & 31) * 4;
+            const int64_t node = n0 + kk;
+            ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (node < ke) {
+                const int ci = i0 + c, cj = j0 + c;
+                if constexpr (VEC4) {
+                    if (ci < M) ra[p] = ci < HD ? *reinterpret_cast<const float4*>(gPL + node * HD + ci)
+                                                : *reinterpret_cast<const float4*>(gPR + node * HD + (ci - HD));
+                    if (cj < F) rb[p] = *reinterpret_cast<const float4*>(X + node * F + cj);
+                } else {
+                    float t[4], u[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cc = ci + q, jj = cj + q;
+                        t[q] = cc < M ? (cc < HD ? gPL[node * HD + cc] : gPR[node * HD + (cc - HD)]) : 0.f;
+                        u[q] = jj < F ? X[node * F + jj] : 0.f;
+                    }
+                    ra[p] = make_float4(t[0], t[1], t[2], t[3]);
+                    rb[p] = make_float4(u[0], u[1], u[2], u[3]);
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = tid + 256 * p;
+            const int kk = idx >> 5, c = (idx & 31) * 4;
+            *reinterpret_cast<float4*>(&As[buf][kk][c]) = ra[p];
+            *reinterpret_cast<float4*>(&Bs[buf][kk][c]) = rb[p];
+        }
+    };
+
+    const int64_t ntile = (ke - kb + KT - 1) / KT;
+    if (ntile > 0) {
+        load_tile(kb);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int64_t t = 0; t < ntile; ++t) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < ntile) load_tile(kb + (t + 1) * KT);
+#pragma unroll 4
+        for (int ks = 0; ks < KT / 2; ++ks) {
+            const int kk = ks * 2 + half;
+            float a[2], b[2];
+            a[0] = As[buf][kk][wm * 64 + li]; a[1] = As[buf][kk][wm * 64 + 32 + li];
+            b[0] = Bs[buf][kk][wn * 64 + li]; b[1] = Bs[buf][kk][wn * 64 + 32 + li];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        if (t + 1 < ntile) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = slabs + (int64_t)blockIdx.z * M * F;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int col = j0 + wn * 64 + y * 32 + li;
+                if (row < M && col < F) out[(int64_t)row * F + col] = acc[x][y][r];
+            }
+}
+
+int64_t grad_w_kchunk(int64_t n_rows, int32_t F, int32_t HD) {
+    const int64_t tiles = ((2 * (int64_t)HD + 127) / 128) * (((int64_t)F + 127) / 128);
+    int64_t splits = 768 / tiles;
+    if (splits < 1) splits = 1;
+    int64_t kchunk = (n_rows + splits - 1) / splits;
+    kchunk = ((kchunk + 31) / 32) * 32;
+    if (kchunk < 256) kchunk = 256;
+    return kchunk;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows, int32_t F,
+                   int32_t HD, hipStream_t s) {
+    ASrcRows as{X, F};
+    BSrcProject bs{W, F, HD};
+    EpiProject ep{PL_rows, PR, HD};
+    const bool vec4 = (F % 4 == 0) && aligned16(X);
+    return run_rowgemm(as, bs, ep, n_rows, 2 * HD, F, vec4, s);
+}
+
+int launch_grad_x(const float* gPL_rows, const float* gPR, const float* W, const float* hpre_prev,
+                  float* gprev, int64_t n_rows, int32_t F, int32_t HD, float slope, hipStream_t s) {
+    ASrcGcat as{gPL_rows, gPR, HD};
+    BSrcGradX bs{W, F, HD};
+    EpiGradX ep{gprev, hpre_prev, F, slope};
+    const bool vec4 = (HD % 4 == 0) && aligned16(gPL_rows) && aligned16(gPR);
+    return run_rowgemm(as, bs, ep, n_rows, F, 2 * HD, vec4, s);
+}
+
+int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD) {
+    const int64_t kchunk = grad_w_kchunk(n_rows, F, HD);
+    const int64_t ksplit = (n_rows + kchunk - 1) / kchunk;
+    return (ksplit < 1 ? 1 : ksplit) * 2 * HD * (int64_t)F;
+}
+
+int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float* gradW, float* scratch,
+                  int64_t n_rows, int32_t F, int32_t HD, hipStream_t s) {
+    if (n_rows <= 0) return 0;
+    const int64_t kchunk = grad_w_kchunk(n_rows, F, HD);
+    const int64_t ksplit = (n_rows + kchunk - 1) / kchunk;
+    const int M = 2 * HD;
+    const dim3 grid((unsigned)((F + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)ksplit);
+    const bool vec4 = (F % 4 == 0) && (HD % 4 == 0) && aligned16(X) && aligned16(gPL_rows) && aligned16(gPR);
+    if (vec4) hipLaunchKernelGGL(gradw_kernel<true>, grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk);
+    else hipLaunchKernelGGL(gradw_kernel<false>, grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk);
+    GAT_HIP(hipGetLastError());
+    return launch_reduce_gradw(scratch, (int32_t)ksplit, HD, F, gradW, s);
+}
+
+}  // namespace gat

@@ -109,6 +109,9 @@ int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* s
 int launch_reduce_partials_add(const float* partial, int32_t nblocks, int64_t width, float* out,
                                hipStream_t s);
 
+// gradW[(c%HD)][(c/HD)*F + f] += sum_z slabs[z][c][f]   (c over 2*HD, fixed order)
+int launch_reduce_gradw(const float* slabs, int32_t ksplit, int32_t HD, int32_t F, float* gradW, hipStream_t s);
+
 // layout converters for taps / op-level entry points
 int launch_transpose_eh_to_he(const float* src_eh, float* dst_he, int64_t E, int32_t H, hipStream_t s);
 int launch_transpose_he_to_eh(const float* src_he, float* dst_eh, int64_t E, int32_t H, hipStream_t s);
