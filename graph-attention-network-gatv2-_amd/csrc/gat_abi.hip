@@ -276,6 +276,8 @@ int gat_create(const gat_config* cfg, gat_ctx** out) {
     c->cfg.heads = c->heads.data();
     c->cfg.outdims = c->outdims.data();
     if (c->cfg.negative_slope == 0.0f) c->cfg.negative_slope = 0.01f;
+    if (!(c->cfg.negative_slope > 0.0f && c->cfg.negative_slope <= 1.0f))
+        return fail(GAT_E_INVALID, "negative_slope must be in (0, 1] (the kernels use LReLU(x) = max(x, slope*x))");
     c->layers.resize(cfg->num_layers);
     int64_t woff = 0, aoff = 0;
     for (int l = 0; l < cfg->num_layers; ++l) {

@@ -49,6 +49,49 @@ __device__ __forceinline__ float group_sum(float t) {
     return t;
 }
 
+// The same all-reduce for N independent values, stage by stage, with the DPP stages written as
+// fused v_add_f32_dpp (hipcc emits v_mov_b32_dpp + v_add + s_nop for the builtin form).  hipcc
+// pads nothing inside asm: the VALU-write -> DPP-read hazard (2 wait states) is covered by one
+// `s_nop 1` per stage — inside a stage consecutive instructions touch different registers, and
+// volatile asm statements keep their order.
+// One stage = ONE asm statement over all N values, so every input is complete before the block and
+// nothing can be scheduled between its instructions.
+#define GAT_DPP_I(i, C) "v_add_f32_dpp %" #i ", %" #i ", %" #i " " C " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define GAT_STR_1(C) GAT_DPP_I(0, C)
+#define GAT_STR_2(C) GAT_STR_1(C) GAT_DPP_I(1, C)
+#define GAT_STR_4(C) GAT_STR_2(C) GAT_DPP_I(2, C) GAT_DPP_I(3, C)
+#define GAT_STR_8(C) GAT_STR_4(C) GAT_DPP_I(4, C) GAT_DPP_I(5, C) GAT_DPP_I(6, C) GAT_DPP_I(7, C)
+#define GAT_STR_16(C) GAT_STR_8(C) GAT_DPP_I(8, C) GAT_DPP_I(9, C) GAT_DPP_I(10, C) GAT_DPP_I(11, C) \
+    GAT_DPP_I(12, C) GAT_DPP_I(13, C) GAT_DPP_I(14, C) GAT_DPP_I(15, C)
+#define GAT_OPS_1 "+v"(t[0])
+#define GAT_OPS_2 GAT_OPS_1, "+v"(t[1])
+#define GAT_OPS_4 GAT_OPS_2, "+v"(t[2]), "+v"(t[3])
+#define GAT_OPS_8 GAT_OPS_4, "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])
+#define GAT_OPS_16 GAT_OPS_8, "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15])
+#define GAT_DPP_STAGE(C)                                                                     \
+    if constexpr (N == 16) asm volatile("s_nop 1\n\t" GAT_STR_16(C) : GAT_OPS_16);           \
+    else if constexpr (N == 8) asm volatile("s_nop 1\n\t" GAT_STR_8(C) : GAT_OPS_8);         \
+    else if constexpr (N == 4) asm volatile("s_nop 1\n\t" GAT_STR_4(C) : GAT_OPS_4);         \
+    else if constexpr (N == 2) asm volatile("s_nop 1\n\t" GAT_STR_2(C) : GAT_OPS_2);         \
+    else asm volatile("s_nop 1\n\t" GAT_STR_1(C) : GAT_OPS_1);
+template <int D, int N>
+__device__ __forceinline__ void group_sum_n(float (&t)[N]) {
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16, "slot count");
+    if constexpr (D >= 2) { GAT_DPP_STAGE("quad_perm:[1,0,3,2]") }
+    if constexpr (D >= 4) { GAT_DPP_STAGE("quad_perm:[2,3,0,1]") }
+    if constexpr (D >= 8) { GAT_DPP_STAGE("row_half_mirror") }
+    if constexpr (D >= 16) { GAT_DPP_STAGE("row_mirror") }
+    if constexpr (D >= 2) asm volatile("s_nop 1");     // asm result -> compiler-scheduled DPP readers
+    if constexpr (D >= 32) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) t[u] += __shfl_xor(t[u], 16);
+    }
+    if constexpr (D >= 64) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) t[u] += __shfl_xor(t[u], 32);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a1: CSR -> COO.  Reference: thread per row, serial over its edges (hub rows serialise).
 // Here: thread per edge, row found by binary search in row_ptr (load-balanced, coalesced stores).
@@ -83,7 +126,7 @@ __device__ __forceinline__ void fwd_write_row(const EdgeFwdArgs& A, int64_t row,
                                               float acc) {
     constexpr int H = HD / D;
     const int c = lane % HD, gidx = lane / HD;
-    const float hp = acc * (1.0f / (Z + 1e-8f));     // E:379 epsilon
+    const float hp = acc * __builtin_amdgcn_rcpf(Z + 1e-8f);     // E:379 epsilon
     if (gidx == 0) {
         A.hpre[row * HD + c] = hp;
         if ((c % D) == 0 && A.mstat != nullptr) {
@@ -105,15 +148,15 @@ __device__ __forceinline__ void fwd_write_row(const EdgeFwdArgs& A, int64_t row,
 // alpha[b..e_end) holds raw log2-domain scores: normalise in place (contiguous [deg][H] slice).
 template <int HD, int D>
 __device__ __forceinline__ void fwd_normalize_slice(const EdgeFwdArgs& A, int b, int e_end, int lane, float m2,
-                                                    float denom) {
+                                                    float inv) {
     constexpr int H = HD / D;
     const int total = (e_end - b) * H;
     float* arow = A.alpha + (int64_t)b * H;
     for (int i0 = 0; i0 < total; i0 += 64) {
         const int i = i0 + lane;
         const int h = i % H;
-        const float mh = __shfl(m2, h * D), dh = __shfl(denom, h * D);
-        if (i < total) arow[i] = exp2_fast(arow[i] - mh) / dh;
+        const float mh = __shfl(m2, h * D), ih = __shfl(inv, h * D);
+        if (i < total) arow[i] = exp2_fast(arow[i] - mh) * ih;
     }
 }
 
@@ -138,15 +181,20 @@ __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_en
     for (int u = 0; u < UU; ++u) {
         const int j = e0 + u * G + gidx;
         const int jc = j < e_end ? j : e_end - 1;
-        const int sid = A.col_idx[jc];
-        v[u] = A.PL[(int64_t)sid * HD + c];
+        const float* prow = A.PL + (int64_t)A.col_idx[jc] * HD;      // wave-uniform when G == 1
+        v[u] = prow[c];
     }
+    // scores: the cross-lane stages run slot-interleaved (UU independent DPP chains), so that no
+    // stage waits on the VALU->DPP hazard of its own predecessor
+    float t[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) { const float s = v[u] + pr; t[u] = ac2 * fmaxf(s, s * A.slope); }
+    group_sum_n<D, UU>(t);
     float cm = -INFINITY;
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
         const int j = e0 + u * G + gidx;
-        const float t = group_sum<D>(ac2 * lrelu(v[u] + pr, A.slope));
-        sc[u] = (j < e_end_v) ? t : -INFINITY;
+        sc[u] = (j < e_end_v) ? t[u] : -INFINITY;
         cm = fmaxf(cm, sc[u]);
     }
     const float mn = fmaxf(m, cm);
@@ -161,10 +209,11 @@ __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_en
     }
     m = mn;
     if (multi) {                                     // park raw scores; normalised later
+        float* ap = A.alpha + (int64_t)e0 * H + (gidx * H + c / D);
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
             const int j = e0 + u * G + gidx;
-            if ((c % D) == 0 && j < e_end_v) A.alpha[(int64_t)j * H + c / D] = sc[u];
+            if ((c % D) == 0 && j < e_end_v) ap[u * G * H] = sc[u];
         }
     }
 }
@@ -223,17 +272,18 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
         }
         return;
     }
-    const float denom = Z + 1e-8f;
+    const float inv = __builtin_amdgcn_rcpf(Z + 1e-8f);      // E:379; v_rcp_f32 (1 ulp) instead of a divide
     if (!multi) {                                    // whole row still in registers
+        float* ap = A.alpha + (int64_t)b * H + (gidx * H + c / D);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = b + u * G + gidx;
-            if ((c % D) == 0 && j < e_end_v) A.alpha[(int64_t)j * H + c / D] = exp2_fast(sc[u] - m) / denom;
+            if ((c % D) == 0 && j < e_end_v) ap[u * G * H] = exp2_fast(sc[u] - m) * inv;
         }
     } else {
         // raw scores were written by other lanes of this wave: drain the stores, then sweep
         __threadfence_block();
-        fwd_normalize_slice<HD, D>(A, b, e_end, lane, m, denom);
+        fwd_normalize_slice<HD, D>(A, b, e_end, lane, m, inv);
     }
     fwd_write_row<HD, D>(A, row, lane, m, Z, acc);
 }
@@ -261,7 +311,7 @@ __global__ __launch_bounds__(256) void edge_fwd_fix_kernel(EdgeFwdArgs A) {
         acc = acc * s1 + as * s2;
         m = mn;
     }
-    fwd_normalize_slice<HD, D>(A, item.y, item.z, lane, m, Z + 1e-8f);
+    fwd_normalize_slice<HD, D>(A, item.y, item.z, lane, m, __builtin_amdgcn_rcpf(Z + 1e-8f));
     if (slot == info.y) fwd_write_row<HD, D>(A, info.x, lane, m, Z, acc);
 }
 
@@ -287,20 +337,25 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
         const int j = e0 + u * G + gidx;
         const int jc = j < e_end ? j : e_end - 1;                // clamped: loads need no predicate
         const int src = A.col_idx[jc];
-        v[u] = A.PL[(int64_t)src * HD + c];
-        al[u] = A.alpha[(int64_t)jc * H + c / D];
+        const float* prow = A.PL + (int64_t)src * HD;            // wave-uniform when G == 1
+        const float* arow = A.alpha + (int64_t)jc * H;
+        v[u] = prow[c];
+        al[u] = arow[c / D];
         if constexpr (STORE) sid[u] = A.pos[jc]; else sid[u] = src;
     }
+    float ga_[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) ga_[u] = g * v[u];
+    group_sum_n<D, UU>(ga_);                                     // galpha, slot-interleaved DPP stages
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
         const int j = e0 + u * G + gidx;
         const bool valid = j < e_end_v;
-        const float galpha = group_sum<D>(g * v[u]);
-        const float ge = valid ? al[u] * (galpha - dot) : 0.f;   // padded slots contribute nothing
+        const float ge = valid ? al[u] * (ga_[u] - dot) : 0.f;   // padded slots contribute nothing
         const float s = v[u] + pr;
         const bool pos = s > 0.f;
         const float gs = ge * ac * (pos ? 1.0f : A.slope);
-        ga = fmaf(ge, pos ? s : s * A.slope, ga);
+        ga = fmaf(ge, fmaxf(s, s * A.slope), ga);
         gpr += gs;
         const float msg = fmaf(g, al[u], gs);                    // d/dPL[src] from this edge
         if (valid) {
@@ -557,8 +612,10 @@ int launch_edge_forward(const EdgeFwdArgs& a, hipStream_t s) {
 }
 
 int edge_backward_blocks(int64_t n_rows) {
+    // 5 blocks (20 waves) per CU are resident with the kernel's ~67 VGPRs / ~106 SGPRs: a grid of
+    // exactly that size has no second, under-occupied round of blocks.
     const int64_t want = (n_rows + 3) / 4;
-    return (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    return (int)(want < 1 ? 1 : (want > 1280 ? 1280 : want));
 }
 
 static int fast_probe(const int&, hipStream_t) { return 1; }
