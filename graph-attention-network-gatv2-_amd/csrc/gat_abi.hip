@@ -177,15 +177,15 @@ static int ensure_buffers(gat_ctx* c) {
         Layer& y = c->layers[l];
         if (!y.PL_bound) GAT_TRY(dalloc(c, &y.PL, T * y.HD));
         GAT_TRY(dalloc(c, &y.PR, N * y.HD));
-        GAT_TRY(dalloc(c, &y.alpha, E * y.H));
+        // attn_coeff [E][H] is only materialised for parity taps and for layers on the generic
+        // path; the fast path's backward recomputes it from the per-(row, head) softmax stats.
+        if (c->cfg.keep_taps || !edge_fast_path(y.H, y.D)) GAT_TRY(dalloc(c, &y.alpha, E * y.H));
         GAT_TRY(dalloc(c, &y.hpre, N * y.HD));
         GAT_TRY(dalloc(c, &y.hout, N * (l == L - 1 ? y.D : y.HD)));
         GAT_TRY(dalloc(c, &y.g, N * y.HD));
-        if (c->cfg.keep_taps) {
-            GAT_TRY(dalloc(c, &y.ge, E * y.H));
-            GAT_TRY(dalloc(c, &y.mstat, N * y.H));
-            GAT_TRY(dalloc(c, &y.zstat, N * y.H));
-        }
+        GAT_TRY(dalloc(c, &y.mstat, N * y.H));
+        GAT_TRY(dalloc(c, &y.zstat, N * y.H));
+        if (c->cfg.keep_taps) GAT_TRY(dalloc(c, &y.ge, E * y.H));
     }
     if (!c->gPL_bound) GAT_TRY(dalloc(c, &c->gPL, T * c->HDmax));
     GAT_TRY(dalloc(c, &c->gPR, N * c->HDmax));
@@ -219,8 +219,7 @@ static int ensure_buffers(gat_ctx* c) {
             (void)hipGetLastError();      // not enough HBM for the scratch: atomics variant
         }
     }
-    c->ga_blocks = edge_backward_blocks(N);
-    GAT_TRY(dalloc(c, &c->ga_partial, (int64_t)c->ga_blocks * c->HDmax));
+    GAT_TRY(dalloc(c, &c->ga_partial, (int64_t)2048 * c->HDmax));      // >= any edge_backward_blocks()
     int64_t gw = 1;
     for (int l = 0; l < L; ++l) gw = std::max(gw, grad_w_scratch_floats(N, c->layers[l].F, c->layers[l].HD));
     GAT_TRY(dalloc(c, &c->gw_scratch, gw));
@@ -548,11 +547,15 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     }
     EdgeBwdArgs a{};
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
-    a.alpha = y.alpha; a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge;
+    a.alpha = y.alpha; a.mstat = y.mstat; a.zstat = y.zstat;
+    a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge;
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
     a.part_acc = c->part_acc;
-    a.ga_partial = c->ga_partial; a.ga_blocks = c->ga_blocks; a.n_rows = c->n_rows; a.H = y.H; a.D = y.D;
+    { const char* dbg = getenv("GAT_DBG"); a.dbg = dbg ? atoi(dbg) : 0; }
+    a.ga_partial = c->ga_partial; a.n_rows = c->n_rows; a.H = y.H; a.D = y.D;
+    a.ga_blocks = edge_fast_path(y.H, y.D) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr)
+                                           : edge_backward_blocks(c->n_rows * 4, y.H, y.D, false, false);
     a.slope = c->cfg.negative_slope;
     {
         Scope t(c, GAT_K_EDGE_BWD);
@@ -563,7 +566,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
         GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, y.HD, c->stream));
     }
     Scope t(c, GAT_K_MISC);
-    return launch_reduce_partials_add(c->ga_partial, c->ga_blocks, y.HD, ga_of(c, l), c->stream);
+    return launch_reduce_partials_add(c->ga_partial, a.ga_blocks, y.HD, ga_of(c, l), c->stream);
 }
 
 int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
@@ -701,8 +704,16 @@ int gat_tap(gat_ctx* c, int tensor, int32_t l, void* host, int64_t count) {
             return rc;
         }
         case GAT_TAP_ALPHA: GAT_TRY(need(E * y.H)); return transposed(y.alpha, E, y.H, true);
+        case GAT_TAP_MAX: {
+            GAT_TRY(need(N * y.H));
+            GAT_TRY(transposed(y.mstat, N, y.H, false));
+            if (edge_fast_path(y.H, y.D)) {          // kept in the log2 domain on the device
+                float* f = static_cast<float*>(host);
+                for (int64_t i = 0; i < N * y.H; ++i) f[i] = std::max(f[i] * 0.6931471805599453f, -1e9f);
+            }
+            return 0;
+        }
         case GAT_TAP_GE: GAT_TRY(need(E * y.H)); return transposed(y.ge, E, y.H, true);
-        case GAT_TAP_MAX: GAT_TRY(need(N * y.H)); return transposed(y.mstat, N, y.H, false);
         case GAT_TAP_SUM: GAT_TRY(need(N * y.H)); return transposed(y.zstat, N, y.H, false);
         case GAT_TAP_HPRE: GAT_TRY(need(N * y.HD)); return d2h(c, host, y.hpre, N * y.HD * sizeof(float));
         case GAT_TAP_HOUT: { const int64_t n = N * (last ? y.D : y.HD); GAT_TRY(need(n)); return d2h(c, host, y.hout, n * sizeof(float)); }
@@ -759,11 +770,13 @@ int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, con
     hipStream_t s = (hipStream_t)stream;
     const int HD = h * d;
     TmpBufs t;
-    float *PL, *PR, *alpha;
+    float *PL, *PR, *alpha, *ms, *zs;
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
+    GAT_TRY(t.get(&ms, n * h)); GAT_TRY(t.get(&zs, n * h));
     GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, s));
     EdgeFwdArgs a{};
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
+    a.mstat = ms; a.zstat = zs;
     a.hpre = d_hpre; a.hout = d_hout; a.n_rows = n; a.H = h; a.D = d; a.is_last = is_last; a.slope = slope;
     GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
     a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots;
@@ -784,22 +797,38 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     const int HD = h * d;
     TmpBufs t;
     float *PL, *PR, *alpha, *gPL, *gPR, *gap, *scr;
-    const int blocks = edge_backward_blocks(n);
+    const int blocks = 2048;      // capacity; the grid actually used is computed below
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
     GAT_TRY(t.get(&gPL, n * HD)); GAT_TRY(t.get(&gPR, n * HD)); GAT_TRY(t.get(&gap, (int64_t)blocks * HD));
     GAT_TRY(t.get(&scr, grad_w_scratch_floats(n, f, HD)));
     GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, s));
     GAT_TRY(launch_transpose_he_to_eh(d_attn_coeff, alpha, e, h, s));
+    GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
+    // softmax stats of this layer (the fast-path backward recomputes alpha from them): one
+    // forward edge pass into scratch outputs
+    float *ms, *zs, *hp_tmp, *ho_tmp;
+    GAT_TRY(t.get(&ms, n * h)); GAT_TRY(t.get(&zs, n * h)); GAT_TRY(t.get(&hp_tmp, n * HD)); GAT_TRY(t.get(&ho_tmp, n * HD));
+    {
+        EdgeFwdArgs fa{};
+        fa.row_ptr = d_row_ptr; fa.col_idx = d_col_idx; fa.PL = PL; fa.PR = PR; fa.a = d_a;
+        fa.alpha = edge_fast_path(h, d) ? nullptr : alpha; fa.hpre = hp_tmp; fa.hout = ho_tmp; fa.mstat = ms; fa.zstat = zs;
+        fa.n_rows = n; fa.H = h; fa.D = d; fa.is_last = 0; fa.slope = slope;
+        fa.items = t.items; fa.n_items = t.w.n_items; fa.slot_info = t.slot_info; fa.n_slots = t.w.n_slots;
+        fa.part_acc = t.part_acc; fa.part_mz = t.part_mz;
+        GAT_TRY(launch_edge_forward(fa, s));
+    }
     GAT_HIP(hipMemsetAsync(gPL, 0, (size_t)n * HD * sizeof(float), s));
     EdgeBwdArgs a{};
+    a.mstat = ms; a.zstat = zs;
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
-    a.hpre = d_hpre; a.g = d_g; a.gPL = gPL; a.gPR = gPR; a.ge = nullptr; a.ga_partial = gap; a.ga_blocks = blocks;
+    a.hpre = d_hpre; a.g = d_g; a.gPL = gPL; a.gPR = gPR; a.ge = nullptr; a.ga_partial = gap;
+    a.ga_blocks = edge_fast_path(h, d) ? edge_backward_blocks(t.w.n_items, h, d, false, false)
+                                       : edge_backward_blocks(n * 4, h, d, false, false);
     a.n_rows = n; a.H = h; a.D = d; a.slope = slope;
-    GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
     a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots;
     a.part_acc = t.part_acc;
     GAT_TRY(launch_edge_backward(a, s));
-    GAT_TRY(launch_reduce_partials_add(gap, blocks, HD, d_grad_a, s));
+    GAT_TRY(launch_reduce_partials_add(gap, a.ga_blocks, HD, d_grad_a, s));
     GAT_TRY(launch_grad_w(gPL, gPR, d_x, d_grad_w, scr, n, f, HD, s));
     if (d_hpre_prev && d_g_prev) GAT_TRY(launch_grad_x(gPL, gPR, d_w, d_hpre_prev, d_g_prev, n, f, HD, slope, s));
     GAT_HIP(hipStreamSynchronize(s));

@@ -51,14 +51,22 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 // loss_n = -log(max(y[label],1e-12)); correct_n = (argmax == label).  One thread per node, the
 // block's y tile lives in LDS ([NB][ldz], ldz odd) and is written back coalesced.  All tile index
 // arithmetic is 32-bit and incremental (no per-element division).
+// DLP = D_last padded to 8/16/32/64 (the node's H_L row is held in registers, W_o rows are padded
+// with zeros in LDS); DLP = 0 is the any-size fallback that re-reads the row from memory.
+template <int DLP>
 __global__ __launch_bounds__(256) void head_forward_kernel(HeadArgs A, int32_t NB, int32_t ldz) {
     extern __shared__ float lds[];
-    float* s_wo = lds;                               // [C*DL]
-    float* s_z = lds + A.C * A.DL;                   // [NB][ldz]
+    constexpr int DLS = DLP > 0 ? DLP : 1;
+    const int C = A.C, DL = A.DL;
+    const int wstride = DLP > 0 ? DLP : DL;
+    float* s_wo = lds;                               // [C][wstride]
+    float* s_z = lds + C * wstride;                  // [NB][ldz]
     __shared__ double s_loss[4];
     __shared__ int32_t s_corr[4];
-    const int C = A.C, DL = A.DL;
-    for (int i = threadIdx.x; i < C * DL; i += blockDim.x) s_wo[i] = A.Wo[i];
+    for (int i = threadIdx.x; i < C * wstride; i += blockDim.x) {
+        const int c = i / wstride, j = i % wstride;
+        s_wo[i] = j < DL ? A.Wo[c * DL + j] : 0.f;
+    }
     __syncthreads();
     double loss_acc = 0.0;
     int corr_acc = 0;
@@ -72,11 +80,24 @@ __global__ __launch_bounds__(256) void head_forward_kernel(HeadArgs A, int32_t N
             float* zr = s_z + t * ldz;
             const float* x = A.HL + n * DL;
             float mv = -INFINITY;
-            for (int c = 0; c < C; ++c) {
-                float acc = 0.f;
-                for (int j = 0; j < DL; ++j) acc += s_wo[c * DL + j] * x[j];
-                zr[c] = acc;
-                mv = fmaxf(mv, acc);
+            if constexpr (DLP > 0) {
+                float xr[DLS];
+#pragma unroll
+                for (int j = 0; j < DLS; ++j) xr[j] = j < DL ? x[j] : 0.f;
+                for (int c = 0; c < C; ++c) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < DLS; ++j) acc += s_wo[c * DLS + j] * xr[j];   // ascending j (E:496-498)
+                    zr[c] = acc;
+                    mv = fmaxf(mv, acc);
+                }
+            } else {
+                for (int c = 0; c < C; ++c) {
+                    float acc = 0.f;
+                    for (int j = 0; j < DL; ++j) acc += s_wo[c * DL + j] * x[j];
+                    zr[c] = acc;
+                    mv = fmaxf(mv, acc);
+                }
             }
             float sum = 0.f;
             for (int c = 0; c < C; ++c) { const float ev = expf(zr[c] - mv); zr[c] = ev; sum += ev; }
@@ -276,10 +297,17 @@ int head_blocks(int64_t n_rows) {
 }
 int launch_head_forward(const HeadArgs& a, hipStream_t s) {
     int32_t NB, ldz;
-    GAT_TRY(head_tile(a.C, a.DL, 0, &NB, &ldz));
+    const int dlp = a.DL <= 8 ? 8 : (a.DL <= 16 ? 16 : (a.DL <= 32 ? 32 : (a.DL <= 64 ? 64 : 0)));
+    GAT_TRY(head_tile(a.C, dlp ? dlp : a.DL, 0, &NB, &ldz));
     const int blocks = head_blocks(a.n_rows);
-    const size_t lds = ((size_t)a.C * a.DL + (size_t)NB * ldz) * sizeof(float);
-    hipLaunchKernelGGL(head_forward_kernel, dim3(blocks), dim3(256), lds, s, a, NB, ldz);
+    const size_t lds = ((size_t)a.C * (dlp ? dlp : a.DL) + (size_t)NB * ldz) * sizeof(float);
+    switch (dlp) {
+        case 8: hipLaunchKernelGGL(head_forward_kernel<8>, dim3(blocks), dim3(256), lds, s, a, NB, ldz); break;
+        case 16: hipLaunchKernelGGL(head_forward_kernel<16>, dim3(blocks), dim3(256), lds, s, a, NB, ldz); break;
+        case 32: hipLaunchKernelGGL(head_forward_kernel<32>, dim3(blocks), dim3(256), lds, s, a, NB, ldz); break;
+        case 64: hipLaunchKernelGGL(head_forward_kernel<64>, dim3(blocks), dim3(256), lds, s, a, NB, ldz); break;
+        default: hipLaunchKernelGGL(head_forward_kernel<0>, dim3(blocks), dim3(256), lds, s, a, NB, ldz); break;
+    }
     GAT_HIP(hipGetLastError());
     hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(64), 0, s, a.loss_partial, a.correct_partial, blocks,
                        a.loss_out, a.correct_out);

@@ -20,6 +20,9 @@
 // of an edge are one 4H-byte segment); CSR int32; work items int4 {row, beg, end, slot|-1}.
 #include "gat_internal.h"
 
+#include <map>
+#include <mutex>
+
 namespace gat {
 namespace {
 
@@ -129,8 +132,8 @@ __device__ __forceinline__ void fwd_write_row(const EdgeFwdArgs& A, int64_t row,
     const float hp = acc * __builtin_amdgcn_rcpf(Z + 1e-8f);     // E:379 epsilon
     if (gidx == 0) {
         A.hpre[row * HD + c] = hp;
-        if ((c % D) == 0 && A.mstat != nullptr) {
-            A.mstat[row * H + c / D] = fmaxf(m2 * kLn2, -1e9f);
+        if ((c % D) == 0) {                          // softmax stats, log2 domain: the backward
+            A.mstat[row * H + c / D] = m2;               // recomputes alpha = exp2(score2 - m2)/(Z+eps)
             A.zstat[row * H + c / D] = Z;
         }
     }
@@ -170,7 +173,7 @@ __device__ __forceinline__ int per_lane(int x) {
 
 // One chunk of UU slots per edge group: UU independent gathers issued back to back (indices
 // clamped into the item, so loads need no predicate), then scores, then the online-softmax update.
-template <int HD, int D, int UU, int USC>
+template <int HD, int D, int UU, int USC, bool ALPHA>
 __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_end, int e_end_v, int c, int gidx,
                                           float pr, float ac2, bool multi, float (&sc)[USC], float& m, float& Z,
                                           float& acc) {
@@ -208,7 +211,7 @@ __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_en
         acc = fmaf(p, v[u], acc);
     }
     m = mn;
-    if (multi) {                                     // park raw scores; normalised later
+    if (ALPHA && multi) {                            // park raw scores; normalised later
         float* ap = A.alpha + (int64_t)e0 * H + (gidx * H + c / D);
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
@@ -218,7 +221,8 @@ __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_en
     }
 }
 
-template <int HD, int D>
+// ALPHA: also materialise attn_coeff [E][H] (parity taps only; the training path never needs it).
+template <int HD, int D, bool ALPHA>
 __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
     constexpr int G = 64 / HD;      // edges per wave-instruction
     constexpr int U = 16 / G;       // gathers in flight per group
@@ -244,10 +248,10 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
 
     for (int e0 = b; e0 < e_end; e0 += CH) {
         if constexpr (U >= 2) {
-            if (e_end - e0 <= CH / 2) fwd_chunk<HD, D, U / 2, U>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
-            else fwd_chunk<HD, D, U, U>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
+            if (e_end - e0 <= CH / 2) fwd_chunk<HD, D, U / 2, U, ALPHA>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
+            else fwd_chunk<HD, D, U, U, ALPHA>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
         } else {
-            fwd_chunk<HD, D, U, U>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
+            fwd_chunk<HD, D, U, U, ALPHA>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
         }
     }
 
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
         }
         return;
     }
+    if constexpr (ALPHA) {
     const float inv = __builtin_amdgcn_rcpf(Z + 1e-8f);      // E:379; v_rcp_f32 (1 ulp) instead of a divide
     if (!multi) {                                    // whole row still in registers
         float* ap = A.alpha + (int64_t)b * H + (gidx * H + c / D);
@@ -285,12 +290,13 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
         __threadfence_block();
         fwd_normalize_slice<HD, D>(A, b, e_end, lane, m, inv);
     }
+    }
     fwd_write_row<HD, D>(A, row, lane, m, Z, acc);
 }
 
 // Split rows: one wave per segment merges ALL partials of its row (L2-hot, <= a few hundred
 // bytes each), normalises its own alpha slice, and the row's first segment writes the outputs.
-template <int HD, int D>
+template <int HD, int D, bool ALPHA>
 __global__ __launch_bounds__(256) void edge_fwd_fix_kernel(EdgeFwdArgs A) {
     constexpr int H = HD / D;
     const int lane = threadIdx.x & 63;
@@ -298,6 +304,7 @@ __global__ __launch_bounds__(256) void edge_fwd_fix_kernel(EdgeFwdArgs A) {
     const int slot = blockIdx.x * 4 + wave;
     if (slot >= A.n_slots) return;
     const int4 info = A.slot_info[slot];             // {row, first_slot, nseg, item}
+    if (!ALPHA && slot != info.y) return;            // without alpha only the row outputs remain
     const int4 item = A.items[info.w];
     const int c = lane % HD;
     float m = -1e9f * kLog2e, Z = 0.f, acc = 0.f;
@@ -311,7 +318,7 @@ __global__ __launch_bounds__(256) void edge_fwd_fix_kernel(EdgeFwdArgs A) {
         acc = acc * s1 + as * s2;
         m = mn;
     }
-    fwd_normalize_slice<HD, D>(A, item.y, item.z, lane, m, __builtin_amdgcn_rcpf(Z + 1e-8f));
+    if constexpr (ALPHA) fwd_normalize_slice<HD, D>(A, item.y, item.z, lane, m, __builtin_amdgcn_rcpf(Z + 1e-8f));
     if (slot == info.y) fwd_write_row<HD, D>(A, info.x, lane, m, Z, acc);
 }
 
@@ -325,12 +332,13 @@ __global__ __launch_bounds__(256) void edge_fwd_fix_kernel(EdgeFwdArgs A) {
 //   grad_a += ge LReLU(s)   gPR[dst] += gs   gPL[src] += g alpha + gs   (E:769-782, 859-869)
 // STORE: message row -> its CSC slot (summed per source by gpl_sum_kernel); else float atomics.
 // ------------------------------------------------------------------------------------------------
-template <int HD, int D, int UU, bool STORE, bool TAPS>
+template <int HD, int D, int UU, bool STORE, bool TAPS, int DBG>
 __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_end, int e_end_v, int c, int gidx,
-                                          float g, float pr, float dot, float ac, float& ga, float& gpr) {
+                                          float g, float pr, float dot, float ac, float ac2, float m2, float inv,
+                                          float& ga, float& gpr) {
     constexpr int G = 64 / HD;
     constexpr int H = HD / D;
-    float v[UU], al[UU];
+    float v[UU];
     int sid[UU];            // gPL row (atomics path) or message slot (store path)
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
@@ -338,37 +346,47 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
         const int jc = j < e_end ? j : e_end - 1;                // clamped: loads need no predicate
         const int src = A.col_idx[jc];
         const float* prow = A.PL + (int64_t)src * HD;            // wave-uniform when G == 1
-        const float* arow = A.alpha + (int64_t)jc * H;
         v[u] = prow[c];
-        al[u] = arow[c / D];
-        if constexpr (STORE) sid[u] = A.pos[jc]; else sid[u] = src;
+        if constexpr (STORE) sid[u] = (DBG == 2) ? jc : A.pos[jc]; else sid[u] = src;
     }
-    float ga_[UU];
+    // Compute in passes of P <= 8 slots (bounds the live registers; the first pass starts as soon as
+    // its own gathers have landed).  alpha is recomputed from the forward's per-(row, head) softmax
+    // stats instead of being read back from HBM:
+    //   score2 = sum_k a2 LReLU(s),  alpha = exp2(score2 - m2) / (Z + eps)          (E:378-379)
+    constexpr int P = UU > 8 ? 8 : UU;
 #pragma unroll
-    for (int u = 0; u < UU; ++u) ga_[u] = g * v[u];
-    group_sum_n<D, UU>(ga_);                                     // galpha, slot-interleaved DPP stages
+    for (int p0 = 0; p0 < UU; p0 += P) {
+        float al[P], ga_[P];
 #pragma unroll
-    for (int u = 0; u < UU; ++u) {
-        const int j = e0 + u * G + gidx;
-        const bool valid = j < e_end_v;
-        const float ge = valid ? al[u] * (ga_[u] - dot) : 0.f;   // padded slots contribute nothing
-        const float s = v[u] + pr;
-        const bool pos = s > 0.f;
-        const float gs = ge * ac * (pos ? 1.0f : A.slope);
-        ga = fmaf(ge, fmaxf(s, s * A.slope), ga);
-        gpr += gs;
-        const float msg = fmaf(g, al[u], gs);                    // d/dPL[src] from this edge
-        if (valid) {
-            if constexpr (STORE) A.msg[(int64_t)sid[u] * HD + c] = msg;
-            else unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, msg);
-        }
-        if constexpr (TAPS) {
-            if (valid && (c % D) == 0) A.ge[(int64_t)j * H + c / D] = ge;
+        for (int q = 0; q < P; ++q) { const float s = v[p0 + q] + pr; al[q] = ac2 * fmaxf(s, s * A.slope); }
+        group_sum_n<D, P>(al);
+#pragma unroll
+        for (int q = 0; q < P; ++q) { al[q] = exp2_fast(al[q] - m2) * inv; ga_[q] = g * v[p0 + q]; }
+        group_sum_n<D, P>(ga_);                                  // galpha, slot-interleaved DPP stages
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int u = p0 + q;
+            const int j = e0 + u * G + gidx;
+            const bool valid = j < e_end_v;
+            const float ge = valid ? al[q] * (ga_[q] - dot) : 0.f;   // padded slots contribute nothing
+            const float s = v[u] + pr;
+            const bool pos = s > 0.f;
+            const float gs = ge * ac * (pos ? 1.0f : A.slope);
+            ga = fmaf(ge, fmaxf(s, s * A.slope), ga);
+            gpr += gs;
+            const float msg = fmaf(g, al[q], gs);                // d/dPL[src] from this edge
+            if (valid && DBG != 1) {
+                if constexpr (STORE) A.msg[(int64_t)sid[u] * HD + c] = msg;
+                else unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, msg);
+            }
+            if constexpr (TAPS) {
+                if (valid && (c % D) == 0) A.ge[(int64_t)j * H + c / D] = ge;
+            }
         }
     }
 }
 
-template <int HD, int D, bool STORE, bool TAPS>
+template <int HD, int D, bool STORE, bool TAPS, int DBG = 0>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
     constexpr int G = 64 / HD;
     constexpr int U = 16 / G;
@@ -378,6 +396,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane % HD, gidx = lane / HD;
     const float ac = A.a[c];
+    const float ac2 = ac * kLog2e;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     float ga = 0.f;
 
@@ -389,13 +408,15 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
         const float g = A.g[row * HD + c];
         const float pr = A.PR[row * HD + c];
         const float dot = group_sum<D>(g * A.hpre[row * HD + c]);
+        const float m2 = A.mstat[row * (HD / D) + c / D];
+        const float inv = __builtin_amdgcn_rcpf(A.zstat[row * (HD / D) + c / D] + 1e-8f);
         float gpr = 0.f;
         for (int e0 = b; e0 < e_end; e0 += CH) {
             if constexpr (U >= 2) {
-                if (e_end - e0 <= CH / 2) bwd_chunk<HD, D, U / 2, STORE, TAPS>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ga, gpr);
-                else bwd_chunk<HD, D, U, STORE, TAPS>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ga, gpr);
+                if (e_end - e0 <= CH / 2) bwd_chunk<HD, D, U / 2, STORE, TAPS, DBG>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ac2, m2, inv, ga, gpr);
+                else bwd_chunk<HD, D, U, STORE, TAPS, DBG>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ac2, m2, inv, ga, gpr);
             } else {
-                bwd_chunk<HD, D, U, STORE, TAPS>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ga, gpr);
+                bwd_chunk<HD, D, U, STORE, TAPS, DBG>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ac2, m2, inv, ga, gpr);
             }
         }
 #pragma unroll
@@ -551,19 +572,52 @@ template <int HD, int D>
 int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
     if (a.items == nullptr) return fail(GAT_E_INVALID, "edge_forward: work-item list missing");
     const int64_t blocks = (a.n_items + 3) / 4;
-    hipLaunchKernelGGL((edge_fwd_kernel<HD, D>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    GAT_HIP(hipGetLastError());
-    if (a.n_slots > 0) {
-        hipLaunchKernelGGL((edge_fwd_fix_kernel<HD, D>), dim3((unsigned)((a.n_slots + 3) / 4)), dim3(256), 0, s, a);
-        GAT_HIP(hipGetLastError());
+    if (a.mstat == nullptr || a.zstat == nullptr) return fail(GAT_E_INVALID, "edge_forward: stats buffers missing");
+    const dim3 grid((unsigned)blocks), fgrid((unsigned)((a.n_slots + 3) / 4)), block(256);
+    if (a.alpha != nullptr) {
+        hipLaunchKernelGGL((edge_fwd_kernel<HD, D, true>), grid, block, 0, s, a);
+        if (a.n_slots > 0) hipLaunchKernelGGL((edge_fwd_fix_kernel<HD, D, true>), fgrid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((edge_fwd_kernel<HD, D, false>), grid, block, 0, s, a);
+        if (a.n_slots > 0) hipLaunchKernelGGL((edge_fwd_fix_kernel<HD, D, false>), fgrid, block, 0, s, a);
     }
+    GAT_HIP(hipGetLastError());
     return 0;
 }
+// Blocks of `fn` (256 threads, no dynamic LDS) that are resident on the whole chip at once, from the
+// occupancy API (cached per kernel).  The backward grid is exactly this size: its items are dealt
+// statically, so a second, partially filled round of blocks would be pure tail.
+static int resident_blocks(const void* fn) {
+    static std::mutex mu;
+    static std::map<const void*, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(fn);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (per_cu > 8) per_cu = 8;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipGetLastError();
+    return cache[fn] = per_cu * (cus > 0 ? cus : 256);
+}
+struct BwdSel { bool store, taps; };
+template <int HD, int D>
+int bwd_resident(const BwdSel& sel, hipStream_t) {
+    const void* fn = sel.store ? (sel.taps ? (const void*)edge_bwd_kernel<HD, D, true, true> : (const void*)edge_bwd_kernel<HD, D, true, false>)
+                               : (sel.taps ? (const void*)edge_bwd_kernel<HD, D, false, true> : (const void*)edge_bwd_kernel<HD, D, false, false>);
+    return resident_blocks(fn);
+}
+
 template <int HD, int D>
 int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
     if (a.items == nullptr) return fail(GAT_E_INVALID, "edge_backward: work-item list missing");
     const dim3 grid((unsigned)a.ga_blocks), block(256);
     const bool store = a.pos != nullptr && a.msg != nullptr, taps = a.ge != nullptr;
+    if constexpr (HD == 64 && D == 8) {          // timing experiments (GAT_DBG=1: no message store, 2: sequential slots)
+        if (store && !taps && a.dbg == 1) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 1>), grid, block, 0, s, a); return 0; }
+        if (store && !taps && a.dbg == 2) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 2>), grid, block, 0, s, a); return 0; }
+    }
     if (store && taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, true>), grid, block, 0, s, a);
     else if (store) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false>), grid, block, 0, s, a);
     else if (taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, true>), grid, block, 0, s, a);
@@ -611,11 +665,17 @@ int launch_edge_forward(const EdgeFwdArgs& a, hipStream_t s) {
     return 0;
 }
 
-int edge_backward_blocks(int64_t n_rows) {
-    // 5 blocks (20 waves) per CU are resident with the kernel's ~67 VGPRs / ~106 SGPRs: a grid of
-    // exactly that size has no second, under-occupied round of blocks.
-    const int64_t want = (n_rows + 3) / 4;
-    return (int)(want < 1 ? 1 : (want > 1280 ? 1280 : want));
+int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D_, bool store, bool taps) {
+    int64_t want = (n_items + 3) / 4;
+    if (want < 1) want = 1;
+    const int HD = H * D_, D = D_;
+    const BwdSel sel{store, taps};
+    auto cap = [&]() -> int {
+        GAT_DISPATCH_HD_D(bwd_resident, sel, nullptr)
+        return 2048;                                  // generic path: one wave per block
+    };
+    const int c = cap();
+    return (int)(want < c ? want : c);
 }
 
 static int fast_probe(const int&, hipStream_t) { return 1; }
@@ -634,7 +694,7 @@ bool edge_fast_path(int32_t H, int32_t D_) {
 
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s) {
     const int HD = a.H * a.D, D = a.D;
-    if (a.ga_blocks != edge_backward_blocks(a.n_rows)) return fail(GAT_E_INVALID, "edge_backward: ga_blocks mismatch");
+    if (a.ga_blocks < 1) return fail(GAT_E_INVALID, "edge_backward: ga_blocks must come from edge_backward_blocks()");
     GAT_DISPATCH_HD_D(run_bwd, a, s)
     if (a.pos != nullptr) return fail(GAT_E_INVALID, "edge_backward: the generic path has no store mode");
     const size_t lds = (size_t)(3 * a.H + 2 * HD) * sizeof(float);

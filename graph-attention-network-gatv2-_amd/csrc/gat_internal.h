@@ -36,11 +36,11 @@ struct EdgeFwdArgs {
     const float* PL;          // [n_table][HD]
     const float* PR;          // [n_rows][HD]
     const float* a;           // [HD]
-    float* alpha;             // [E][H]
+    float* alpha;             // [E][H]; fast path: null = do not materialise (training path)
     float* hpre;              // [n_rows][HD]
     float* hout;              // hidden [n_rows][HD]; last [n_rows][D]
-    float* mstat;             // [n_rows][H] or null (tap)
-    float* zstat;             // [n_rows][H] or null (tap)
+    float* mstat;             // [n_rows][H] softmax max per (row, head); fast path: log2 domain
+    float* zstat;             // [n_rows][H] softmax sum
     int64_t n_rows;
     int32_t H, D;
     int32_t is_last;
@@ -73,7 +73,9 @@ struct EdgeBwdArgs {
     const float* PL;          // [n_table][HD]
     const float* PR;          // [n_rows][HD]
     const float* a;           // [HD]
-    const float* alpha;       // [E][H]
+    const float* alpha;       // [E][H]  generic path only (the fast path recomputes it from mstat/zstat)
+    const float* mstat;       // [n_rows][H] forward softmax max (fast path: log2 domain)
+    const float* zstat;       // [n_rows][H] forward softmax sum
     const float* hpre;        // [n_rows][HD]
     const float* g;           // [n_rows][HD]  dL/dh_pre
     float* gPL;               // [n_table][HD]  atomics path only: zeroed by the caller, added into
@@ -91,9 +93,11 @@ struct EdgeBwdArgs {
     const int4* slot_info;
     int32_t n_slots;
     float* part_acc;          // [n_slots][HD]  per-segment gPR partials of split rows
+    int32_t dbg;
 };
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s);
-int edge_backward_blocks(int64_t n_rows);   // grid size used by launch_edge_backward
+// Grid size (== rows of ga_partial) for the backward of an (H, D) layer over n_items work items.
+int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D, bool store, bool taps);
 bool edge_fast_path(int32_t H, int32_t D);  // wave-per-row templates cover this (H, D)
 
 // ---- source-major slot index + segmented sum (gat_csc.hip) ----------------------------------------
