@@ -1,0 +1,301 @@
+// train_edge — drop-in for the reference's edge-based GATv2 trainer (GATv2_edge_based.cu `main`,
+// cited E:<line>): same command-line flags and defaults, same four-text-file CSR dataset, same
+// stdout/stderr lines, but every device operation goes through the C ABI of include/gatv2_abi.h
+// (libgatv2_hip.so: hand-written HIP for MI355X).  This file is plain host C++: no HIP headers.
+//
+//   ./train_edge --dataset cora --data-root /path/to/datasets --num-layers 2 --heads 8,8 \
+//                --outdims 8,8 --epochs 20 --optimizer adam --lr 0.01 --clip
+//
+// Additive flags (not in the reference): --seed N (parameter init; default time(NULL) like
+// E:1305), --load-params FILE / --dump-params FILE (raw fp32: W | a | Wo in the reference
+// layouts), --device N.
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "gatv2_abi.h"
+
+namespace {
+
+struct Options {
+    int epochs = 200;                 // E:935
+    int layers = 2;                   // E:936
+    bool clip = false;                // E:937
+    std::string optimizer = "sgd";    // E:938
+    float lr = 0.0001f, beta1 = 0.9f, beta2 = 0.999f;   // E:939
+    bool beta1_given = false, beta2_given = false;
+    std::vector<int32_t> heads, outdims;
+    bool heads_given = false, outdims_given = false;
+    std::string dataset = "pubmed";   // E:1050
+    std::string data_root = "./data"; // E:1051
+    // additive
+    uint64_t seed = 0; bool seed_given = false;
+    std::string load_params, dump_params;
+    int device = 0;
+};
+
+[[noreturn]] void die(const std::string& msg) {
+    std::cerr << msg;
+    std::exit(1);
+}
+
+bool split_ints(const std::string& csv, int count, std::vector<int32_t>& out) {
+    out.clear();
+    std::stringstream ss(csv);
+    std::string item;
+    for (int i = 0; i < count; ++i) {
+        if (!std::getline(ss, item, ',')) return false;
+        out.push_back(std::stoi(item));
+    }
+    return true;
+}
+
+// The reference scans argv three times (E:943-953, 958-1010, 1053-1061): --num-layers is looked
+// up first so that --heads/--outdims can be sized; unknown flags are ignored.
+Options parse_args(int argc, char** argv) {
+    Options o;
+    for (int i = 1; i + 1 < argc; ++i)
+        if (std::string(argv[i]) == "--num-layers") {
+            o.layers = std::stoi(argv[i + 1]);
+            if (o.layers <= 0) die("Error: Number of layers must be > 0\n");
+            break;
+        }
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        const bool has_val = i + 1 < argc;
+        if (a == "--epochs" && has_val) o.epochs = std::stoi(argv[++i]);
+        else if (a == "--heads" && has_val) {
+            if (!split_ints(argv[++i], o.layers, o.heads))
+                die("Error: --heads must have " + std::to_string(o.layers) + " values.\n");
+            o.heads_given = true;
+        } else if (a == "--outdims" && has_val) {
+            if (!split_ints(argv[++i], o.layers, o.outdims))
+                die("Error: --ooutdims must have " + std::to_string(o.layers) + " values.\n");   // sic, E:982
+            o.outdims_given = true;
+        } else if (a == "--clip") o.clip = true;
+        else if (a == "--optimizer" && has_val) {
+            o.optimizer = argv[++i];
+            if (o.optimizer != "sgd" && o.optimizer != "adam") die("Invalid optimizer choice. Use 'sgd' or 'adam'\n");
+        } else if (a == "--beta1" && has_val) { o.beta1 = std::stof(argv[++i]); o.beta1_given = true; }
+        else if (a == "--beta2" && has_val) { o.beta2 = std::stof(argv[++i]); o.beta2_given = true; }
+        else if (a == "--lr" && has_val) o.lr = std::stof(argv[++i]);
+        else if (a == "--dataset" && has_val) o.dataset = argv[++i];
+        else if (a == "--data-root" && has_val) o.data_root = argv[++i];
+        else if (a == "--seed" && has_val) { o.seed = std::strtoull(argv[++i], nullptr, 0); o.seed_given = true; }
+        else if (a == "--load-params" && has_val) o.load_params = argv[++i];
+        else if (a == "--dump-params" && has_val) o.dump_params = argv[++i];
+        else if (a == "--device" && has_val) o.device = std::stoi(argv[++i]);
+    }
+    if (o.optimizer == "adam") {
+        if (o.beta1 <= 0.0f || o.beta1 >= 1.0f || o.beta2 <= 0.0f || o.beta2 >= 1.0f)
+            die("Error: For Adam optimizer, beta1 and beta2 must be in (0,1).\n");
+    } else if (o.beta1_given || o.beta2_given) {
+        std::cerr << "Warning: beta1/beta2 specified but ignored for SGD optimizer.\n";
+    }
+    // The reference leaves head[]/out_dim[] uninitialised without these flags.
+    if (!o.heads_given) die("Error: --heads must have " + std::to_string(o.layers) + " values.\n");
+    if (!o.outdims_given) die("Error: --ooutdims must have " + std::to_string(o.layers) + " values.\n");
+    const char* env_root = std::getenv("DATA_ROOT");             // E:1064-1067
+    if (env_root && o.data_root == "./data") o.data_root = env_root;
+    if (!o.data_root.empty() && o.data_root.back() != '/' && o.data_root.back() != '\\') o.data_root += '/';
+    return o;
+}
+
+// ---- dataset text files (R:20-27; E:24-64) ----------------------------------------------------
+// Whole-file read + strtof/strtol scanning: the reference's iostream loaders are the start-up
+// bottleneck on large graphs; the accepted syntax (whitespace separated numbers) is the same.
+bool slurp(const std::string& path, std::string& out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { out.clear(); return false; }
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    out = ss.str();
+    return true;
+}
+
+void load_features(const std::string& path, std::vector<float>& x, int64_t& n, int& dim) {
+    std::string buf;
+    slurp(path, buf);
+    n = 0; dim = 0;
+    const char* p = buf.c_str();
+    const char* end = p + buf.size();
+    while (p < end) {
+        const char* eol = static_cast<const char*>(memchr(p, '\n', end - p));
+        if (!eol) eol = end;
+        int count = 0;
+        const char* q = p;
+        while (q < eol) {
+            char* next = nullptr;
+            const float v = std::strtof(q, &next);
+            if (next == q || next > eol) break;
+            x.push_back(v);
+            ++count;
+            q = next;
+        }
+        if (dim == 0) dim = count;
+        else if (count != dim) {
+            std::cerr << "Inconsistent input_dim on line " << n << std::endl;   // E:43
+            std::exit(1);
+        }
+        ++n;
+        p = eol + 1;
+    }
+}
+
+void load_ints(const std::string& path, std::vector<int32_t>& v) {
+    std::string buf;
+    slurp(path, buf);
+    const char* p = buf.c_str();
+    for (;;) {
+        char* next = nullptr;
+        const long val = std::strtol(p, &next, 10);
+        if (next == p) break;
+        v.push_back((int32_t)val);
+        p = next;
+    }
+}
+
+void check(int rc, const char* what) {
+    if (rc != 0) {
+        std::fprintf(stderr, "Error launching %s: %s\n", what, gat_last_error());   // style of E:1191 …, but fatal
+        std::exit(1);
+    }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    size_t free_before = 0, total_mem = 0;
+    if (gat_mem_info(&free_before, &total_mem) != 0)       // like the reference: report and go on (E:1189-1192)
+        std::fprintf(stderr, "Error launching gat_mem_info: %s\n", gat_last_error());
+    std::printf("\n[Memory Tracker] Before allocation:\n");
+    std::printf("  Total GPU memory: %.2f MB\n", total_mem / (1024.0 * 1024.0));
+    std::printf("  Free GPU memory : %.2f MB\n", free_before / (1024.0 * 1024.0));
+
+    const Options o = parse_args(argc, argv);
+    const int L = o.layers;
+    std::cout << "Configuration:\n"
+              << "  Number of layers: " << L << "\n"
+              << "  Epochs: " << o.epochs << "\n"
+              << "  Attention heads: [";
+    for (int l = 0; l < L; ++l) std::cout << o.heads[l] << (l < L - 1 ? ", " : "");
+    std::cout << "]\n  Output dimensions: [";
+    for (int l = 0; l < L; ++l) std::cout << o.outdims[l] << (l < L - 1 ? ", " : "");
+    std::cout << "]\n"
+              << "  Gradient clipping: " << (o.clip ? "true" : "false") << "\n"
+              << "  Optimizer: " << o.optimizer << "\n"
+              << "  Learning rate: " << o.lr << "\n\n";
+
+    const std::string path = o.data_root + o.dataset + "/";
+    std::cout << "Using dataset: " << o.dataset << std::endl;
+    std::cout << "Dataset path: " << path << std::endl;
+
+    std::vector<float> x;
+    int64_t N = 0; int F0 = 0;
+    load_features(path + "features.txt", x, N, F0);
+    std::vector<int32_t> row_ptr, col_idx, labels;
+    load_ints(path + "row_ptr.txt", row_ptr);
+    if ((int64_t)row_ptr.size() != N + 1) { std::cerr << "Invalid row_ptr length\n"; return 1; }
+    load_ints(path + "col_idx.txt", col_idx);
+    const int64_t E = (int64_t)col_idx.size();
+    load_ints(path + "labels.txt", labels);
+    if ((int64_t)labels.size() != N) { std::cerr << "Invalid labels length\n"; return 1; }
+
+    int max_degree = 0;
+    for (int64_t i = 0; i < N; ++i) max_degree = std::max(max_degree, row_ptr[i + 1] - row_ptr[i]);
+    std::cout << "Max degree = " << max_degree << std::endl;
+    const int C = *std::max_element(labels.begin(), labels.end()) + 1;          // E:1106-1107
+    std::cout << "Number of classes = " << C << std::endl;
+    std::cout << "Graph loaded: " << N << " nodes, " << E << " edges, "
+              << "input_feature_vector_dim = " << F0 << std::endl;
+
+    // ---- the reference's buffer-size report (E:1153-1350), same formulas ----
+    std::vector<int64_t> in_dim(L);
+    in_dim[0] = F0;
+    for (int l = 1; l < L; ++l) in_dim[l] = (int64_t)o.heads[l - 1] * o.outdims[l - 1];
+    const size_t fsz = sizeof(float);
+    std::printf("\nsize of input features : %zu MB\n", (size_t)(N * F0 * fsz) / (1024 * 1024));
+    std::printf("\nsize of graph data (CSR,COO, labels) : %zu KB\n",
+                (size_t)(((N + 1) + E + N + 2 * E) * sizeof(int)) / 1024);
+    size_t total_out = 0, total_heads = 0, total_w = 0, total_a = 0, total_ig = 0;
+    for (int l = 0; l < L; ++l) {
+        total_out += (l == L - 1) ? (size_t)N * o.outdims[l] : (size_t)N * o.heads[l] * o.outdims[l];
+        total_heads += o.heads[l];
+        total_w += (size_t)o.heads[l] * o.outdims[l] * 2 * in_dim[l];
+        total_a += (size_t)o.heads[l] * o.outdims[l];
+        total_ig += (size_t)N * o.heads[l] * o.outdims[l] * fsz;
+    }
+    const int max_heads = *std::max_element(o.heads.begin(), o.heads.end());
+    std::printf("\nTotal size of layer outputs(pre & post activation): %zu MB\n", (2 * total_out * fsz) / (1024 * 1024));
+    std::printf("Total size of attention scores & coeffs: %zu MB\n", (2 * total_heads * E * fsz) / (1024 * 1024));
+    std::printf("\nTotal size of parameters and their gradients: %zu MB\n",
+                ((total_w + total_a + (size_t)C * o.outdims[L - 1]) * 2 * fsz) / (1024 * 1024));
+    std::printf("\nloss and accuracy storage: %zu MB\n", ((size_t)N * (sizeof(float) + sizeof(int))) / (1024 * 1024));
+    std::printf("Total size of intermediate gradients: %zu MB\n",
+                ((total_ig + (size_t)max_heads * E * 2) * fsz) / (1024 * 1024));     // E:1350 (its 4x quirk kept)
+
+    // ---- device context ----
+    gat_config cfg{};
+    cfg.num_layers = L; cfg.heads = o.heads.data(); cfg.outdims = o.outdims.data();
+    cfg.in_dim = F0; cfg.num_classes = C; cfg.negative_slope = 0.01f; cfg.device = o.device;
+    gat_ctx* ctx = nullptr;
+    check(gat_create(&cfg, &ctx), "gat_create");
+    check(gat_set_graph(ctx, row_ptr.data(), col_idx.data(), N, E, N, 0), "csr_to_coo_kernel");
+    check(gat_set_features(ctx, x.data(), N, F0), "gat_set_features");
+    check(gat_set_labels(ctx, labels.data(), N), "gat_set_labels");
+    check(gat_params_init(ctx, o.seed_given ? o.seed : (uint64_t)time(nullptr)), "xavier_init_kernel");
+    int64_t nW = 0, nA = 0, nWo = 0;
+    gat_param_count(ctx, GAT_PARAM_W, &nW); gat_param_count(ctx, GAT_PARAM_A, &nA); gat_param_count(ctx, GAT_PARAM_WO, &nWo);
+    if (!o.load_params.empty()) {
+        std::vector<float> p(nW + nA + nWo);
+        std::ifstream f(o.load_params, std::ios::binary);
+        if (!f.read(reinterpret_cast<char*>(p.data()), p.size() * sizeof(float))) die("Error: cannot read --load-params file\n");
+        check(gat_params_set(ctx, GAT_PARAM_W, p.data(), nW), "gat_params_set");
+        check(gat_params_set(ctx, GAT_PARAM_A, p.data() + nW, nA), "gat_params_set");
+        check(gat_params_set(ctx, GAT_PARAM_WO, p.data() + nW + nA, nWo), "gat_params_set");
+    }
+
+    size_t free_after = 0;
+    check(gat_mem_info(&free_after, &total_mem), "gat_mem_info");
+    std::printf("\n[Memory Tracker] After all allocations:\n");
+    std::printf("  Free GPU memory : %.2f MB\n", free_after / (1024.0 * 1024.0));
+    std::printf("  Approx. GPU memory allocated by this program: %.2f MB\n",
+                (double)(free_before - free_after) / (1024.0 * 1024.0));
+
+    check(gat_zero_grad(ctx), "gat_zero_grad");
+    for (int epoch = 1; epoch <= o.epochs; ++epoch) {
+        const auto start = std::chrono::high_resolution_clock::now();
+        std::printf("\nEpoch %d\n", epoch);
+        float loss_sum = 0.f; int32_t n_correct = 0;
+        check(gat_forward(ctx, &loss_sum, &n_correct), "gatv2 forward");
+        std::printf("\nAvg Loss: %f, Accuracy: %.2f%%\n", loss_sum / N, 100.0f * (static_cast<float>(n_correct) / N));
+        check(gat_backward(ctx), "gatv2 backward");
+        if (o.clip) check(gat_clip(ctx, 5.0f), "clip_grad_norm");                   // E:1563
+        if (o.optimizer == "adam") check(gat_step_adam(ctx, o.lr, o.beta1, o.beta2, 1e-8f, epoch), "adam_update_kernel");
+        else check(gat_step_sgd(ctx, o.lr), "sgd_update_kernel");
+        check(gat_zero_grad(ctx), "gat_zero_grad");
+        check(gat_sync(ctx), "gat_sync");
+        const std::chrono::duration<double, std::milli> elapsed = std::chrono::high_resolution_clock::now() - start;
+        std::cout << " total time: " << elapsed.count() << " ms" << std::endl;
+    }
+
+    if (!o.dump_params.empty()) {
+        std::vector<float> p(nW + nA + nWo);
+        check(gat_params_get(ctx, GAT_PARAM_W, p.data(), nW), "gat_params_get");
+        check(gat_params_get(ctx, GAT_PARAM_A, p.data() + nW, nA), "gat_params_get");
+        check(gat_params_get(ctx, GAT_PARAM_WO, p.data() + nW + nA, nWo), "gat_params_get");
+        std::ofstream f(o.dump_params, std::ios::binary);
+        f.write(reinterpret_cast<const char*>(p.data()), p.size() * sizeof(float));
+    }
+    gat_destroy(ctx);
+    return 0;
+}

@@ -4,7 +4,7 @@ gradients 1e-4 (fp32 order effects: 1e-3) of the tensor's max-abs."""
 import numpy as np
 import pytest
 
-from conftest import small_graph
+from conftest import grad_close, small_graph
 
 pytestmark = pytest.mark.gpu
 
@@ -36,6 +36,11 @@ def _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo, **kw):
 
 def _relerr(got, ref):
     return float(np.abs(got - ref).max() / max(1e-6, np.abs(ref).max()))
+
+
+def _gclose(got, ref, what=""):
+    ok, info = grad_close(got, ref, GTOL)
+    assert ok, (what, info)
 
 
 CASES = [
@@ -70,11 +75,11 @@ def test_step_parity(pkg, orc, heads, outdims, f, n, e, hub, empty):
         assert abs(loss - ref.loss_sum_f64) / n < TOL
         assert correct == ref.n_correct
         for l in range(cfg.L - 1, -1, -1):
-            assert _relerr(ctx.tap(A.TAP_G, l), ref.taps["g"][l]) < GTOL, f"g l={l}"
-            assert _relerr(ctx.tap(A.TAP_GE, l), ref.taps["ge"][l]) < GTOL, f"ge l={l}"
-        assert _relerr(ctx.grads_get(A.PARAM_WO), ref.gradWo) < GTOL
-        assert _relerr(ctx.grads_get(A.PARAM_A), ref.grada) < GTOL
-        assert _relerr(ctx.grads_get(A.PARAM_W), ref.gradW) < GTOL
+            _gclose(ctx.tap(A.TAP_G, l), ref.taps["g"][l], f"g l={l}")
+            _gclose(ctx.tap(A.TAP_GE, l), ref.taps["ge"][l], f"ge l={l}")
+        _gclose(ctx.grads_get(A.PARAM_WO), ref.gradWo, "gradWo")
+        _gclose(ctx.grads_get(A.PARAM_A), ref.grada, "grada")
+        _gclose(ctx.grads_get(A.PARAM_W), ref.gradW, "gradW")
     finally:
         ctx.close()
 
@@ -86,8 +91,8 @@ def test_flat_lrelu_index_mode(pkg, orc):
     ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo, flat_lrelu_index=True)
     ctx, _, _ = _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo, flat_lrelu_index=True)
     try:
-        assert _relerr(ctx.grads_get(A.PARAM_W), ref.gradW) < GTOL
-        assert _relerr(ctx.grads_get(A.PARAM_A), ref.grada) < GTOL
+        _gclose(ctx.grads_get(A.PARAM_W), ref.gradW, "gradW")
+        _gclose(ctx.grads_get(A.PARAM_A), ref.grada, "grada")
     finally:
         ctx.close()
 
@@ -160,8 +165,8 @@ def test_op_level_entry_points(pkg, orc):
     rc = lib.gat_op_layer_backward(p(d_rp), p(d_ci), p(d_x), p(Wl), p(al), p(d_alpha), p(d_hpre), p(d_g), p(gw), p(ga),
                                    None, None, n, e, f, H, D, C.c_float(0.01), None)
     assert rc == 0, lib.gat_last_error()
-    assert _relerr(gw.cpu().numpy(), ref.gradW[cfg.w_offsets[0]:cfg.w_offsets[1]]) < GTOL
-    assert _relerr(ga.cpu().numpy(), ref.grada[cfg.a_offsets[0]:cfg.a_offsets[1]]) < GTOL
+    _gclose(gw.cpu().numpy(), ref.gradW[cfg.w_offsets[0]:cfg.w_offsets[1]], "op gradW")
+    _gclose(ga.cpu().numpy(), ref.grada[cfg.a_offsets[0]:cfg.a_offsets[1]], "op grada")
 
 
 def test_error_paths(pkg):

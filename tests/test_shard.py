@@ -1,0 +1,141 @@
+"""N>1 path: destination-range sharding + the three exchanges, on CPU with gloo (world_size 2 and
+3) against the single-process oracle; and, with -m gpu, two ranks sharing the one GPU of the test
+box with the real HIP contexts (gloo stages the exchanges through the host)."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import grad_close, small_graph
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem(seed=3, n=90, e=700, f=12, c=4, heads=(8, 8), outdims=(8, 8)):
+    rng = np.random.default_rng(seed)
+    rp, ci = small_graph(rng, n, e, hub=(5, 150), empty=(0, 44))
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    lab = rng.integers(0, c, n).astype(np.int32)
+    lab[0] = c - 1
+    return dict(rp=rp, ci=ci, x=x, lab=lab, f=f, c=c, heads=list(heads), outdims=list(outdims), n=n)
+
+
+def test_partition_and_remap(pkg):
+    S = pkg.shard
+    P = _problem()
+    for world in (1, 2, 3, 5):
+        plans = [S.make_plan(P["rp"], world, r) for r in range(world)]
+        b = plans[0].bounds
+        assert b[0] == 0 and b[-1] == P["n"] and np.all(np.diff(b) >= 1)
+        edges = [int(P["rp"][b[r + 1]] - P["rp"][b[r]]) for r in range(world)]
+        assert sum(edges) == len(P["ci"])
+        assert max(edges) <= len(P["ci"]) / world + np.diff(P["rp"]).max()      # edge-balanced up to one row
+        for r, pl in enumerate(plans):
+            rp_l, ci_l = S.local_csr(pl, P["rp"], P["ci"])
+            assert rp_l[0] == 0 and rp_l[-1] == edges[r] and len(rp_l) == pl.n_rows + 1
+            # table ids map back to the global sources (CSR->COO stays bit-exact per shard)
+            assert np.array_equal(pl.from_table_ids(ci_l), P["ci"][P["rp"][b[r]]:P["rp"][b[r + 1]]])
+            assert ci_l.max(initial=0) < pl.n_table and pl.table_row0 == r * pl.max_rows
+
+
+def test_fake_context_matches_oracle_single_rank(pkg, orc):
+    """The numpy stand-in used by the gloo tests is itself checked against the literal oracle."""
+    from fake_ctx import FakeContext
+    P = _problem()
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    W, a, Wo = orc.xavier_params(cfg, 11)
+    ref = orc.step(cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo)
+    import torch
+    ctx = FakeContext(P["heads"], P["outdims"], P["f"], P["c"])
+    ctx.set_graph(P["rp"], P["ci"]); ctx.set_features(P["x"]); ctx.set_labels(P["lab"])
+    for g, arr in enumerate((W, a, Wo)):
+        ctx.params_set(g, arr)
+    plan = pkg.shard.make_plan(P["rp"], 1, 0)
+
+    class NoComm:
+        native = False
+        def all_gather_rows(self, t, w): pass
+        def reduce_scatter_rows(self, t, w): pass
+        def all_reduce_(self, t): return t
+    run = pkg.shard.ShardedGat(ctx, plan, NoComm(), P["heads"], P["outdims"], alloc=lambda k: torch.zeros(k))
+    loss, correct = run.forward()
+    run.backward()
+    assert abs(loss - ref.loss_sum_f64) < 1e-4 * P["n"] and correct == ref.n_correct
+    got = run.grads.numpy()
+    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    ok, info = grad_close(got, want, 1e-4, frac=0.02)
+    assert ok, info
+
+
+def _worker(rank, world, port, outdir, use_gpu):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    pkg = entry.load_package(); orc = entry.load_oracle()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = _problem()
+        cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+        W, a, Wo = orc.xavier_params(cfg, 11)
+        S = pkg.shard
+        plan = S.make_plan(P["rp"], world, rank)
+        rp_l, ci_l = S.local_csr(plan, P["rp"], P["ci"])
+        lo, hi = plan.row0, plan.row0 + plan.n_rows
+        if use_gpu:
+            dev = torch.device("cuda", 0)
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream(device=dev)
+            cm = torch.cuda.stream(stream)
+            cm.__enter__()
+            ctx = pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"], device=0, stream=stream.cuda_stream)
+            alloc = lambda k: torch.zeros(k, dtype=torch.float32, device=dev)
+        else:
+            from fake_ctx import FakeContext
+            ctx = FakeContext(P["heads"], P["outdims"], P["f"], P["c"])
+            alloc = lambda k: torch.zeros(k)
+        ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
+        ctx.set_features(P["x"][lo:hi]); ctx.set_labels(P["lab"][lo:hi])
+        for g, arr in enumerate((W, a, Wo)):
+            ctx.params_set(g, arr)
+        ctx.zero_grad()
+        run = S.ShardedGat(ctx, plan, S.TorchComm(), P["heads"], P["outdims"], alloc=alloc)
+        loss, correct = run.forward()
+        run.backward()
+        grads = run.grads.cpu().numpy()
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), loss=loss, correct=correct, grads=grads)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world(world, use_gpu, pkg, orc):
+    import torch.multiprocessing as mp
+    P = _problem()
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    W, a, Wo = orc.xavier_params(cfg, 11)
+    ref = orc.step(cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo)
+    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    port = 29500 + (os.getpid() % 2000) + world
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, port, d, use_gpu), nprocs=world, join=True)
+        outs = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
+    for o in outs:       # every rank holds the global loss and the all-reduced gradients
+        assert abs(float(o["loss"]) - ref.loss_sum_f64) < 1e-4 * P["n"]
+        assert int(o["correct"]) == ref.n_correct
+        ok, info = grad_close(o["grads"], want, 2e-4, frac=0.02)
+        assert ok, info
+    assert np.array_equal(outs[0]["grads"], outs[-1]["grads"])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_step_gloo_cpu(pkg, orc, world):
+    _run_world(world, False, pkg, orc)
+
+
+@pytest.mark.gpu
+def test_sharded_step_two_ranks_one_gpu(pkg, orc):
+    """The real HIP contexts, sharded 2-way on the single GPU of the box (exchanges via gloo)."""
+    _run_world(2, True, pkg, orc)

@@ -1,0 +1,110 @@
+"""The C++ host `train_edge` (drop-in for the reference binary): CLI contract on CPU, and with
+-m gpu whole epochs (forward, loss line, backward, clip, optimizer) against the oracle driven
+through the same sequence (E:1370-1642)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "graph-attention-network-gatv2-_amd", "train_edge")
+
+
+def run(args, env=None):
+    e = dict(os.environ)
+    e.pop("DATA_ROOT", None)
+    if env:
+        e.update(env)
+    return subprocess.run([BIN] + args, capture_output=True, text=True, env=e, timeout=600)
+
+
+def test_binary_exists():
+    assert os.path.exists(BIN), "run __graft_entry__.build()"
+
+
+@pytest.mark.parametrize("args,msg", [
+    (["--num-layers", "0"], "Error: Number of layers must be > 0\n"),
+    (["--num-layers", "2", "--heads", "8"], "Error: --heads must have 2 values.\n"),
+    (["--num-layers", "2", "--heads", "8,8", "--outdims", "8"], "Error: --ooutdims must have 2 values.\n"),
+    (["--heads", "8,8", "--outdims", "8,8", "--optimizer", "rmsprop"], "Invalid optimizer choice. Use 'sgd' or 'adam'\n"),
+    (["--heads", "8,8", "--outdims", "8,8", "--optimizer", "adam", "--beta1", "1.5"],
+     "Error: For Adam optimizer, beta1 and beta2 must be in (0,1).\n"),
+    (["--heads", "8,8"], "Error: --ooutdims must have 2 values.\n"),        # no defaults exist
+])
+def test_cli_errors(args, msg):
+    r = run(args)
+    assert r.returncode == 1
+    assert r.stderr.endswith(msg), r.stderr
+
+
+def test_cli_config_echo_and_missing_dataset(tmp_path):
+    r = run(["--num-layers", "3", "--heads", "4,1,1", "--outdims", "64,32,16", "--epochs", "20", "--optimizer", "adam",
+             "--lr", "0.01", "--clip", "--dataset", "citeseer", "--data-root", str(tmp_path)])
+    assert ("Configuration:\n  Number of layers: 3\n  Epochs: 20\n  Attention heads: [4, 1, 1]\n"
+            "  Output dimensions: [64, 32, 16]\n  Gradient clipping: true\n  Optimizer: adam\n"
+            "  Learning rate: 0.01\n\n") in r.stdout
+    assert f"Using dataset: citeseer\nDataset path: {tmp_path}/citeseer/\n" in r.stdout
+    assert r.returncode == 1 and "Invalid row_ptr length\n" in r.stderr       # unopened files -> length 0 (E:1084)
+    r = run(["--heads", "8,8", "--outdims", "8,8", "--beta1", "0.5"], env={"DATA_ROOT": str(tmp_path)})
+    assert "Warning: beta1/beta2 specified but ignored for SGD optimizer.\n" in r.stderr
+    assert f"Dataset path: {tmp_path}/pubmed/\n" in r.stdout                   # env DATA_ROOT + default dataset
+
+
+def test_inconsistent_feature_rows(tmp_path):
+    d = tmp_path / "bad"
+    d.mkdir()
+    (d / "features.txt").write_text("1 2 3\n4 5\n")
+    for f in ("row_ptr.txt", "col_idx.txt", "labels.txt"):
+        (d / f).write_text("0\n")
+    r = run(["--heads", "8,8", "--outdims", "8,8", "--dataset", "bad", "--data-root", str(tmp_path)])
+    assert r.returncode == 1 and "Inconsistent input_dim on line 1" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("optimizer,clip", [("adam", True), ("sgd", False)])
+def test_epochs_match_oracle(pkg, orc, tmp_path, optimizer, clip):
+    ds = pkg.synth.make_dataset("cora", scale=0.15)
+    pkg.synth.write_text_dataset(ds, str(tmp_path), "tiny")
+    # the loaders parse text: use exactly what the binary will read
+    x = np.loadtxt(tmp_path / "tiny" / "features.txt", dtype=np.float32, ndmin=2)
+    heads, outdims = [8, 8], [8, 8]
+    cfg = orc.Config(heads, outdims, ds["f"], ds["c"])
+    W, a, Wo = orc.xavier_params(cfg, 7)
+    pfile = tmp_path / "p.bin"
+    np.concatenate([W, a, Wo]).astype(np.float32).tofile(pfile)
+    epochs, lr = 3, (0.01 if optimizer == "adam" else 1e-3)
+    args = ["--dataset", "tiny", "--data-root", str(tmp_path), "--num-layers", "2", "--heads", "8,8", "--outdims", "8,8",
+            "--epochs", str(epochs), "--optimizer", optimizer, "--lr", str(lr), "--load-params", str(pfile),
+            "--dump-params", str(tmp_path / "out.bin")] + (["--clip"] if clip else [])
+    r = run(args)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert f"Graph loaded: {ds['n']} nodes, {ds['e']} edges, input_feature_vector_dim = {ds['f']}\n" in out
+    assert f"Number of classes = {ds['c']}\n" in out and f"Max degree = {int(np.diff(ds['row_ptr']).max())}\n" in out
+    assert "[Memory Tracker] After all allocations:" in out and out.count(" total time: ") == epochs
+    got = [(float(m.group(1)), float(m.group(2))) for m in re.finditer(r"Avg Loss: ([0-9.]+), Accuracy: ([0-9.]+)%", out)]
+    assert len(got) == epochs
+    # the oracle through the same epoch loop (intended semantics: zeroed h_pre each pass)
+    L = orc.lib()
+    ms = [np.zeros_like(p) for p in (W, a, Wo)]; vs = [np.zeros_like(p) for p in (W, a, Wo)]
+    params = [W.copy(), a.copy(), Wo.copy()]
+    for ep in range(1, epochs + 1):
+        ref = orc.step(cfg, ds["row_ptr"], ds["col_idx"], ds["labels"], x, *params)
+        assert abs(got[ep - 1][0] - ref.loss_sum_f32 / ds["n"]) < 1e-4, (ep, got[ep - 1], ref.loss_sum_f32 / ds["n"])
+        assert abs(got[ep - 1][1] - 100.0 * ref.n_correct / ds["n"]) < 0.011
+        grads = [ref.gradW, ref.grada, ref.gradWo]
+        for i in range(3):
+            if clip:
+                L.orc_clip_grad_norm(grads[i], grads[i].size, 5.0)
+            if optimizer == "adam":
+                L.orc_adam(params[i], grads[i], ms[i], vs[i], lr, params[i].size, 0.9, 0.999, 1e-8, ep)
+            else:
+                L.orc_sgd(params[i], grads[i], lr, params[i].size)
+    final = np.fromfile(tmp_path / "out.bin", dtype=np.float32)
+    want = np.concatenate(params)
+    if optimizer == "sgd":
+        assert np.abs(final - want).max() < 1e-4
+    else:   # Adam's first steps are ~lr*sign(g): an entry whose gradient is ~0 may step the other way
+        assert (np.abs(final - want) > 5e-3).mean() < 0.005
