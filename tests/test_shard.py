@@ -125,7 +125,7 @@ def _run_world(world, use_gpu, pkg, orc):
     for o in outs:       # every rank holds the global loss and the all-reduced gradients
         assert abs(float(o["loss"]) - ref.loss_sum_f64) < 1e-4 * P["n"]
         assert int(o["correct"]) == ref.n_correct
-        ok, info = grad_close(o["grads"], want, 2e-4, frac=0.02)
+        ok, info = grad_close(o["grads"], want, 1e-3 if use_gpu else 2e-4, frac=0.02)   # fp32 HIP vs fp64 stand-in
         assert ok, info
     assert np.array_equal(outs[0]["grads"], outs[-1]["grads"])
 
