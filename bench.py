@@ -77,6 +77,23 @@ def cpu_baseline(pkg, workload, heads, outdims, sample_scale):
     }
 
 
+def measured_traffic(args, world, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/traffic.json,
+    collected with tools/pmc_traffic.sh on this workload at N=1): PMC counters cannot be read from inside
+    the benchmark process, so the figure is attached only when workload and scale match, else null."""
+    if world != 1 or args.scale != 1.0:
+        return None
+    best = None
+    for path in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
+        if t.get("workload") == args.workload and kernel in t.get("kernels", {}):
+            best = t["kernels"][kernel]["bytes_per_launch"]
+    return best
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,7 +116,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        kw = {"device_id": dev} if args.backend == "nccl" else {}
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
 
     # ---- synthetic inputs (same on every rank; each keeps its destination range) ----
     t_gen = time.perf_counter()
@@ -107,7 +125,12 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         ctx = pkg.GatContext(heads, outdims, f, c, device=local_rank, stream=stream.cuda_stream, collect_timing=True)
-        if world == 1:
+        force_sharded = os.environ.get("GAT_FORCE_SHARDED") == "1"     # rehearse the N>1 code path on one GPU
+        if world == 1 and force_sharded:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group(backend=args.backend, rank=0, world_size=1)
+        if world == 1 and not force_sharded:
             ctx.set_graph(row_ptr, col_idx)
             ctx.set_features(pkg.synth.features(n, f, kind=kind))
             ctx.set_labels(pkg.synth.labels(n, c))
@@ -191,7 +214,7 @@ def main():
                               "achieved_GBps": bytes_step_all / (dt / args.steps) / 1e9 / world,
                               "frac_of_8TBps_per_gpu": bytes_step_all / (dt / args.steps) / 1e9 / world / HBM_PEAK_GBS},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world, dom),
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in stats.items() if v[0] > 0},
         }
