@@ -185,7 +185,7 @@ __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_en
         const int j = e0 + u * G + gidx;
         const int jc = j < e_end ? j : e_end - 1;
         const float* prow = A.PL + (int64_t)A.col_idx[jc] * HD;      // wave-uniform when G == 1
-        v[u] = prow[c];
+        v[u] = prow[(unsigned)c];
     }
     // scores: the cross-lane stages run slot-interleaved (UU independent DPP chains), so that no
     // stage waits on the VALU->DPP hazard of its own predecessor
@@ -346,7 +346,7 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
         const int jc = j < e_end ? j : e_end - 1;                // clamped: loads need no predicate
         const int src = A.col_idx[jc];
         const float* prow = A.PL + (int64_t)src * HD;            // wave-uniform when G == 1
-        v[u] = prow[c];
+        v[u] = prow[(unsigned)c];
         if constexpr (STORE) sid[u] = (DBG == 2) ? jc : A.pos[jc]; else sid[u] = src;
     }
     // Compute in passes of P <= 8 slots (bounds the live registers; the first pass starts as soon as
@@ -376,7 +376,7 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
             gpr += gs;
             const float msg = fmaf(g, al[q], gs);                // d/dPL[src] from this edge
             if (valid && DBG != 1) {
-                if constexpr (STORE) A.msg[(int64_t)sid[u] * HD + c] = msg;
+                if constexpr (STORE) (A.msg + (int64_t)sid[u] * HD)[(unsigned)c] = msg;
                 else unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, msg);
             }
             if constexpr (TAPS) {

@@ -116,7 +116,15 @@ class TorchComm:
         """table: every rank's full-length partial sums; afterwards rank's slice holds the total."""
         t = table.view(self.world, -1)
         if self.native:
-            self.dist.reduce_scatter_tensor(t[self.rank], table, group=self.group)
+            # out-of-place (a slice-sized staging buffer, then one D2D copy into the rank's slice):
+            # an output that aliases the input is legal for RCCL but not guaranteed by every
+            # torch.distributed version, and the copy is ~1/P of the table
+            n = t[self.rank].numel()
+            if getattr(self, "_rs_out", None) is None or self._rs_out.numel() < n:
+                self._rs_out = table.new_empty(n)
+            out = self._rs_out[:n]
+            self.dist.reduce_scatter_tensor(out, table, group=self.group)
+            t[self.rank].copy_(out)
             return
         host = table.cpu()
         self.dist.all_reduce(host, group=self.group)
