@@ -110,6 +110,8 @@ def main():
     if args.scale != 1.0:
         n, e = max(16, int(n * args.scale)), max(16, int(e * args.scale))
 
+    if os.environ.get("GAT_BENCH_SINGLE_DEVICE") == "1":      # rehearsal: all ranks share GPU 0 (use --backend gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
