@@ -8,7 +8,7 @@
 //
 // Additive flags (not in the reference): --seed N (parameter init; default time(NULL) like
 // E:1305), --load-params FILE / --dump-params FILE (raw fp32: W | a | Wo in the reference
-// layouts), --device N.
+// layouts), --device N, --cache (binary cache of the parsed text files, written next to them).
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -21,6 +21,8 @@
 #include <sstream>
 #include <string>
 #include <vector>
+
+#include <sys/stat.h>
 
 #include "gatv2_abi.h"
 
@@ -41,6 +43,7 @@ struct Options {
     uint64_t seed = 0; bool seed_given = false;
     std::string load_params, dump_params;
     int device = 0;
+    bool cache = false;
 };
 
 [[noreturn]] void die(const std::string& msg) {
@@ -94,6 +97,7 @@ Options parse_args(int argc, char** argv) {
         else if (a == "--load-params" && has_val) o.load_params = argv[++i];
         else if (a == "--dump-params" && has_val) o.dump_params = argv[++i];
         else if (a == "--device" && has_val) o.device = std::stoi(argv[++i]);
+        else if (a == "--cache") o.cache = true;
     }
     if (o.optimizer == "adam") {
         if (o.beta1 <= 0.0f || o.beta1 >= 1.0f || o.beta2 <= 0.0f || o.beta2 >= 1.0f)
@@ -164,6 +168,39 @@ void load_ints(const std::string& path, std::vector<int32_t>& v) {
     }
 }
 
+// ---- binary cache: magic, N, F, E, then the four arrays as raw little-endian data ----------------
+constexpr uint64_t kCacheMagic = 0x3143564154414755ull;   // "UGATAVC1"
+bool newer(const std::string& a, const std::string& b) {
+    struct stat sa{}, sb{};
+    if (stat(a.c_str(), &sa) != 0 || stat(b.c_str(), &sb) != 0) return false;
+    return sa.st_mtime >= sb.st_mtime;
+}
+bool load_cache(const std::string& file, const std::string& dir, std::vector<float>& x, int64_t& n, int& f,
+                std::vector<int32_t>& rp, std::vector<int32_t>& ci, std::vector<int32_t>& lab) {
+    for (const char* t : {"features.txt", "row_ptr.txt", "col_idx.txt", "labels.txt"})
+        if (!newer(file, dir + t)) return false;
+    std::ifstream in(file, std::ios::binary);
+    uint64_t h[4] = {0, 0, 0, 0};
+    if (!in.read(reinterpret_cast<char*>(h), sizeof(h)) || h[0] != kCacheMagic) return false;
+    n = (int64_t)h[1]; f = (int)h[2];
+    x.resize((size_t)n * f); rp.resize(n + 1); ci.resize(h[3]); lab.resize(n);
+    in.read(reinterpret_cast<char*>(x.data()), x.size() * sizeof(float));
+    in.read(reinterpret_cast<char*>(rp.data()), rp.size() * sizeof(int32_t));
+    in.read(reinterpret_cast<char*>(ci.data()), ci.size() * sizeof(int32_t));
+    in.read(reinterpret_cast<char*>(lab.data()), lab.size() * sizeof(int32_t));
+    return (bool)in;
+}
+void save_cache(const std::string& file, const std::vector<float>& x, int64_t n, int f, const std::vector<int32_t>& rp,
+                const std::vector<int32_t>& ci, const std::vector<int32_t>& lab) {
+    std::ofstream out(file, std::ios::binary);
+    const uint64_t h[4] = {kCacheMagic, (uint64_t)n, (uint64_t)f, (uint64_t)ci.size()};
+    out.write(reinterpret_cast<const char*>(h), sizeof(h));
+    out.write(reinterpret_cast<const char*>(x.data()), x.size() * sizeof(float));
+    out.write(reinterpret_cast<const char*>(rp.data()), rp.size() * sizeof(int32_t));
+    out.write(reinterpret_cast<const char*>(ci.data()), ci.size() * sizeof(int32_t));
+    out.write(reinterpret_cast<const char*>(lab.data()), lab.size() * sizeof(int32_t));
+}
+
 void check(int rc, const char* what) {
     if (rc != 0) {
         std::fprintf(stderr, "Error launching %s: %s\n", what, gat_last_error());   // style of E:1191 …, but fatal
@@ -201,14 +238,21 @@ int main(int argc, char** argv) {
 
     std::vector<float> x;
     int64_t N = 0; int F0 = 0;
-    load_features(path + "features.txt", x, N, F0);
     std::vector<int32_t> row_ptr, col_idx, labels;
-    load_ints(path + "row_ptr.txt", row_ptr);
-    if ((int64_t)row_ptr.size() != N + 1) { std::cerr << "Invalid row_ptr length\n"; return 1; }
-    load_ints(path + "col_idx.txt", col_idx);
+    // Optional binary cache of the parsed text files (additive: --cache).  Parsing features.txt is the
+    // start-up bottleneck at Products scale (~2 GB of text); the cache is rewritten whenever a text
+    // file is newer than it.
+    const std::string cache = path + "gatv2_cache.bin";
+    if (!(o.cache && load_cache(cache, path, x, N, F0, row_ptr, col_idx, labels))) {
+        load_features(path + "features.txt", x, N, F0);
+        load_ints(path + "row_ptr.txt", row_ptr);
+        if ((int64_t)row_ptr.size() != N + 1) { std::cerr << "Invalid row_ptr length\n"; return 1; }
+        load_ints(path + "col_idx.txt", col_idx);
+        load_ints(path + "labels.txt", labels);
+        if ((int64_t)labels.size() != N) { std::cerr << "Invalid labels length\n"; return 1; }
+        if (o.cache) save_cache(cache, x, N, F0, row_ptr, col_idx, labels);
+    }
     const int64_t E = (int64_t)col_idx.size();
-    load_ints(path + "labels.txt", labels);
-    if ((int64_t)labels.size() != N) { std::cerr << "Invalid labels length\n"; return 1; }
 
     int max_degree = 0;
     for (int64_t i = 0; i < N; ++i) max_degree = std::max(max_degree, row_ptr[i + 1] - row_ptr[i]);
