@@ -18,6 +18,10 @@
 // slabs summed in fixed order.
 #include "gat_internal.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace gat {
 namespace {
 
@@ -58,20 +62,44 @@ struct BSrcGradX {                // B(k=c, j=f): c < HD ? W[c][f] : W[c-HD][F+f
 };
 // ---- epilogues ---------------------------------------------------------------------------------------
 struct EpiProject {               // cols < HD -> PL rows, else PR
+    static constexpr bool kTwoPhase = false;
     float* PL; float* PR; int32_t HD;
+    __device__ __forceinline__ float pre(int64_t, int) const { return 0.f; }
+    __device__ __forceinline__ void apply(int64_t i, int j, float v, float) const { (*this)(i, j, v); }
     __device__ __forceinline__ void operator()(int64_t i, int j, float v) const {
         if (j < HD) PL[i * HD + j] = v; else PR[i * HD + (j - HD)] = v;
     }
 };
 struct EpiGradX {                 // g_prev = gX ⊙ LReLU'(h_pre_prev)   (E:888-892)
+    // two-phase: all h_pre_prev operands of a tile are loaded first, then all results are stored — a
+    // load/store pair per element is serialised by hipcc (the store may alias the next load)
+    static constexpr bool kTwoPhase = true;
     float* out; const float* hpre_prev; int32_t ld; float slope;
-    __device__ __forceinline__ void operator()(int64_t i, int j, float v) const {
-        const float hv = hpre_prev[i * ld + j];
+    __device__ __forceinline__ float pre(int64_t i, int j) const { return hpre_prev[i * ld + j]; }
+    __device__ __forceinline__ void apply(int64_t i, int j, float v, float hv) const {
         out[i * ld + j] = v * (hv > 0.f ? 1.0f : slope);
     }
+    __device__ __forceinline__ void operator()(int64_t i, int j, float v) const { apply(i, j, v, pre(i, j)); }
 };
 
 constexpr int kKC = 128;          // K chunk resident in LDS
+
+// blocks of a 256-thread kernel resident on the whole chip (occupancy API incl. dynamic LDS), cached
+int64_t resident_blocks(const void* fn, size_t dyn_lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int64_t> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(fn, dyn_lds);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipGetLastError();
+    return cache[key] = (int64_t)per_cu * (cus > 0 ? cus : 256);
+}
 
 // C[M][N] = A[M][K] · B[K][N].  256 threads = 4 waves, each wave owns 32 rows x (NT*32) columns of a
 // 128-row tile; blocks are persistent over row tiles (grid.x) and column blocks of NT*32 (grid.y).
@@ -145,13 +173,27 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(AS as, BS bs, EP ep, int64
             }
         }
         // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        float hv[EP::kTwoPhase ? NT : 1][16];
+        if constexpr (EP::kTwoPhase) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t orow = tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int col = n0 + nt * 32 + li;
+                    hv[nt][r] = (orow < M && col < N) ? ep.pre(orow, col) : 0.f;
+                }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t orow = tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int col = n0 + nt * 32 + li;
-                if (orow < M && col < N) ep(orow, col, acc[nt][r]);
+                if (orow < M && col < N) {
+                    if constexpr (EP::kTwoPhase) ep.apply(orow, col, acc[nt][r], hv[nt][r]);
+                    else ep(orow, col, acc[nt][r]);
+                }
             }
     }
 }
@@ -164,13 +206,17 @@ int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, 
     const int kc_lds = ((K < kKC ? K : kKC) + 7) & ~7;
     const size_t lds = (size_t)kc_lds * NW * sizeof(float);
     const int64_t ntiles = (M + 127) / 128;
-    int per_cu = (int)(160 * 1024 / (lds + 1024));
-    per_cu = per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu);
-    const int64_t gx = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
-    const dim3 grid((unsigned)gx, (unsigned)((N + NW - 1) / NW));
-#define GAT_ROWGEMM(NT_, V_) hipLaunchKernelGGL((rowgemm_kernel<NT_, V_, AS, BS, EP>), grid, dim3(256), lds, s, as, bs, ep, M, N, K, kc_lds)
-    if (vec4) { if (NT == 4) GAT_ROWGEMM(4, true); else if (NT == 2) GAT_ROWGEMM(2, true); else GAT_ROWGEMM(1, true); }
-    else { if (NT == 4) GAT_ROWGEMM(4, false); else if (NT == 2) GAT_ROWGEMM(2, false); else GAT_ROWGEMM(1, false); }
+    // persistent grid = exactly the blocks that are resident at once (registers + LDS, occupancy API):
+    // a larger grid would run a second, partly filled round of 25-tile blocks
+#define GAT_ROWGEMM(NT_, V_)                                                                                  \
+    {                                                                                                         \
+        auto kern = rowgemm_kernel<NT_, V_, AS, BS, EP>;                                                      \
+        const int64_t res = resident_blocks((const void*)kern, lds);                                          \
+        const dim3 grid((unsigned)(ntiles < res ? ntiles : res), (unsigned)((N + NW - 1) / NW));              \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, as, bs, ep, M, N, K, kc_lds);                        \
+    }
+    if (vec4) { if (NT == 4) GAT_ROWGEMM(4, true) else if (NT == 2) GAT_ROWGEMM(2, true) else GAT_ROWGEMM(1, true) }
+    else { if (NT == 4) GAT_ROWGEMM(4, false) else if (NT == 2) GAT_ROWGEMM(2, false) else GAT_ROWGEMM(1, false) }
 #undef GAT_ROWGEMM
     GAT_HIP(hipGetLastError());
     return 0;
@@ -279,7 +325,8 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
 
 int64_t grad_w_kchunk(int64_t n_rows, int32_t F, int32_t HD) {
     const int64_t tiles = ((2 * (int64_t)HD + 127) / 128) * (((int64_t)F + 127) / 128);
-    int64_t splits = 768 / tiles;
+    // split-K over exactly the blocks that fit at once (64 KiB of LDS per block => 2 per CU)
+    int64_t splits = resident_blocks((const void*)gradw_kernel<true>, 0) / tiles;
     if (splits < 1) splits = 1;
     int64_t kchunk = (n_rows + splits - 1) / splits;
     kchunk = ((kchunk + 31) / 32) * 32;
