@@ -299,8 +299,15 @@ int launch_head_forward(const HeadArgs& a, hipStream_t s) {
     int32_t NB, ldz;
     const int dlp = a.DL <= 8 ? 8 : (a.DL <= 16 ? 16 : (a.DL <= 32 ? 32 : (a.DL <= 64 ? 64 : 0)));
     GAT_TRY(head_tile(a.C, dlp ? dlp : a.DL, 0, &NB, &ldz));
-    const int blocks = head_blocks(a.n_rows);
+    int blocks = head_blocks(a.n_rows);
     const size_t lds = ((size_t)a.C * (dlp ? dlp : a.DL) + (size_t)NB * ldz) * sizeof(float);
+    {   // persistent over node tiles: launch only what is resident at once
+        const void* fn = dlp == 8 ? (const void*)head_forward_kernel<8> : dlp == 16 ? (const void*)head_forward_kernel<16>
+                       : dlp == 32 ? (const void*)head_forward_kernel<32> : dlp == 64 ? (const void*)head_forward_kernel<64>
+                                                                                      : (const void*)head_forward_kernel<0>;
+        const int64_t res = resident_blocks(fn, lds);
+        if (res < blocks) blocks = (int)res;
+    }
     switch (dlp) {
         case 8: hipLaunchKernelGGL(head_forward_kernel<8>, dim3(blocks), dim3(256), lds, s, a, NB, ldz); break;
         case 16: hipLaunchKernelGGL(head_forward_kernel<16>, dim3(blocks), dim3(256), lds, s, a, NB, ldz); break;
@@ -324,8 +331,12 @@ int launch_head_backward(const HeadBwdArgs& a, hipStream_t s) {
     GAT_TRY(head_tile(a.C, a.DL, 2 * a.DL, &NB, &ldz));
     const int per_thread = (a.C * a.DL + 255) / 256;
     if (per_thread > 8) return fail(GAT_E_UNSUPPORTED, "output head: num_classes*D_last > 2048");
-    const int blocks = head_bwd_blocks(a.n_rows, a.C, a.DL);
+    int blocks = head_bwd_blocks(a.n_rows, a.C, a.DL);
     const size_t lds = ((size_t)a.C * a.DL + (size_t)NB * (ldz + 2 * a.DL)) * sizeof(float);
+    {
+        const int64_t res = resident_blocks((const void*)head_backward_kernel, lds);
+        if (res < blocks) blocks = (int)res;
+    }
     hipLaunchKernelGGL(head_backward_kernel, dim3(blocks), dim3(256), lds, s, a, NB, ldz, per_thread);
     GAT_HIP(hipGetLastError());
     return launch_reduce_partials_add(a.partial, blocks, (int64_t)a.C * a.DL, a.gradWo, s);

@@ -84,6 +84,8 @@ struct EpiGradX {                 // g_prev = gX ⊙ LReLU'(h_pre_prev)   (E:888
 
 constexpr int kKC = 128;          // K chunk resident in LDS
 
+}  // namespace
+
 // blocks of a 256-thread kernel resident on the whole chip (occupancy API incl. dynamic LDS), cached
 int64_t resident_blocks(const void* fn, size_t dyn_lds) {
     static std::mutex mu;
@@ -100,6 +102,8 @@ int64_t resident_blocks(const void* fn, size_t dyn_lds) {
     (void)hipGetLastError();
     return cache[key] = (int64_t)per_cu * (cus > 0 ? cus : 256);
 }
+
+namespace {
 
 // C[M][N] = A[M][K] · B[K][N].  256 threads = 4 waves, each wave owns 32 rows x (NT*32) columns of a
 // 128-row tile; blocks are persistent over row tiles (grid.x) and column blocks of NT*32 (grid.y).

@@ -116,6 +116,11 @@ int launch_reduce_partials_add(const float* partial, int32_t nblocks, int64_t wi
 // gradW[(c%HD)][(c/HD)*F + f] += sum_z slabs[z][c][f]   (c over 2*HD, fixed order)
 int launch_reduce_gradw(const float* slabs, int32_t ksplit, int32_t HD, int32_t F, float* gradW, hipStream_t s);
 
+// Blocks of a 256-thread kernel that are resident on the whole chip at once (occupancy API incl.
+// dynamic LDS; cached).  Persistent kernels use exactly this grid: a larger one runs a second,
+// partly filled round of blocks.
+int64_t resident_blocks(const void* fn, size_t dyn_lds);
+
 // layout converters for taps / op-level entry points
 int launch_transpose_eh_to_he(const float* src_eh, float* dst_he, int64_t E, int32_t H, hipStream_t s);
 int launch_transpose_he_to_eh(const float* src_he, float* dst_eh, int64_t E, int32_t H, hipStream_t s);
