@@ -82,6 +82,7 @@ struct gat_ctx {
     int32_t* csc_pos = nullptr;                     // [E] slot of each CSR edge in source-major order
     int32_t* csc_ptr = nullptr;                     // [n_table+1]
     float* msg = nullptr; int32_t msg_hd = 0;       // [E][msg_hd] per-edge message rows (store path)
+    int32_t dbg = 0;                                // GAT_DBG timing experiments (0 = product behaviour)
     gat::WorkList work;                             // host copy of the item list
     int4* items = nullptr; int4* slot_info = nullptr;
     float* part_acc = nullptr; float* part_mz = nullptr;
@@ -293,6 +294,7 @@ int gat_create(const gat_config* cfg, gat_ctx** out) {
     }
     c->nW = woff; c->nA = aoff;
     c->nWo = (int64_t)cfg->num_classes * c->layers.back().D;
+    if (const char* d = getenv("GAT_DBG")) c->dbg = atoi(d);
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { GAT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     gat_ctx* p = c.get();
@@ -552,7 +554,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
     a.part_acc = c->part_acc;
-    { const char* dbg = getenv("GAT_DBG"); a.dbg = dbg ? atoi(dbg) : 0; }
+    a.dbg = c->dbg;
     a.ga_partial = c->ga_partial; a.n_rows = c->n_rows; a.H = y.H; a.D = y.D;
     a.ga_blocks = edge_fast_path(y.H, y.D) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr)
                                            : edge_backward_blocks(c->n_rows * 4, y.H, y.D, false, false);

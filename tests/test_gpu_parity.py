@@ -183,3 +183,44 @@ def test_error_paths(pkg):
             ctx.set_labels(np.array([0, 5], np.int32))             # label outside classes
     finally:
         ctx.close()
+
+
+def test_degenerate_graphs(pkg, orc):
+    """No edges at all; a single node with a self-loop; a graph whose only edges sit in one hub row."""
+    A = pkg.abi
+    rng = np.random.default_rng(4)
+    cases = [
+        (np.zeros(9, np.int32), np.zeros(0, np.int32), 8),                                   # E = 0
+        (np.array([0, 1], np.int32), np.array([0], np.int32), 1),                             # N = 1, self loop
+        (np.concatenate([[0], np.full(20, 300)]).astype(np.int32), np.sort(rng.integers(0, 20, 300)).astype(np.int32), 20),
+    ]
+    for rp, ci, n in cases:
+        x = rng.standard_normal((n, 6)).astype(np.float32)
+        lab = (np.arange(n) % 3).astype(np.int32); lab[0] = 2
+        cfg = orc.Config([8, 8], [8, 8], 6, 3)
+        W, a, Wo = orc.xavier_params(cfg, 3)
+        ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+        ctx, loss, correct = _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo)
+        try:
+            assert np.isfinite(loss) and abs(loss - ref.loss_sum_f64) / n < TOL and correct == ref.n_correct
+            assert _relerr(ctx.tap(A.TAP_HPRE, 1), ref.taps["hpre"][1]) < TOL or np.abs(ref.taps["hpre"][1]).max() == 0
+            _gclose(ctx.grads_get(A.PARAM_W), ref.gradW, "gradW")
+            _gclose(ctx.grads_get(A.PARAM_WO), ref.gradWo, "gradWo")
+        finally:
+            ctx.close()
+
+
+def test_wide_heads_generic_path(pkg, orc):
+    """README example shape (heads 4,1,1 / outdims 64,32,16): H*D = 256 runs the generic kernels."""
+    A = pkg.abi
+    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 31, 60, 333, (4, 1, 1), (64, 32, 16), 24, 6, hub=(2, 40))
+    ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+    ctx, loss, correct = _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo)
+    try:
+        assert abs(loss - ref.loss_sum_f64) / 60 < TOL and correct == ref.n_correct
+        for l in range(3):
+            assert np.abs(ctx.tap(A.TAP_ALPHA, l) - ref.taps["alpha"][l]).max() < TOL
+        _gclose(ctx.grads_get(A.PARAM_W), ref.gradW, "gradW")
+        _gclose(ctx.grads_get(A.PARAM_A), ref.grada, "grada")
+    finally:
+        ctx.close()
