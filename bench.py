@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--workload", default="products", choices=sorted(PRESETS))
     ap.add_argument("--scale", type=float, default=1.0, help="shrink nodes and edges (debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange-layer0", action="store_true",
+                    help="N>1: do not replicate the input features; all-gather / reduce-scatter layer 0 too (A/B)")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0 = auto (~15 s of CPU work)")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--beta", type=float, default=0.75, help="power-law exponent of the degree law (debug)")
@@ -149,7 +151,10 @@ def main():
             rp_l, ci_l = S.local_csr(plan, row_ptr, col_idx)
             lo, hi = plan.row0, plan.row0 + plan.n_rows
             ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
-            ctx.set_features(pkg.synth.features(n, f, rows=(lo, hi), kind=kind))
+            if args.exchange_layer0:     # A/B: exchange layer 0 like the hidden layers
+                ctx.set_features(pkg.synth.features(n, f, rows=(lo, hi), kind=kind))
+            else:                        # static input replicated on every rank: layer 0 runs without exchanges
+                ctx.set_source_features(plan.table_features(pkg.synth.features(n, f, kind=kind)))
             ctx.set_labels(pkg.synth.labels(n, c, rows=(lo, hi)))
             comm = S.TorchComm()
             runner = S.ShardedGat(ctx, plan, comm, heads, outdims,
@@ -215,7 +220,9 @@ def main():
             "config": {
                 "workload": f"{args.workload}-shape synthetic power-law graph, {n} nodes / {e} edges / {f} feat / "
                             f"{c} classes, {len(heads)}-layer GATv2 heads {heads} outdims {outdims}, fp32",
-                "parallelism": f"dst-range x{world}" if world > 1 else "single GPU",
+                "parallelism": (f"dst-range x{world}, " + ("all layers exchanged" if args.exchange_layer0 else
+                                "input features replicated (layer 0 exchange-free)")) if runner is not None
+                               else "single GPU",
                 "loss_per_node": loss / n, "setup_s": round(t_gen, 1), "upload_and_index_s": round(t_up, 2),
             },
             "step_roofline": {"algorithmic_GB_per_step": bytes_step_all / 1e9,

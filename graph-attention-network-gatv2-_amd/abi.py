@@ -109,6 +109,8 @@ def _declare(lib: C.CDLL) -> None:
         "gat_set_graph_device": [vp, vp, vp, i64, i64, i64, i64],
         "gat_set_features_device": [vp, vp, i64, i32],
         "gat_set_labels_device": [vp, vp, i64],
+        "gat_set_source_features": [vp, vp, i64, i32],
+        "gat_set_source_features_device": [vp, vp, i64, i32],
         "gat_param_count": [vp, C.c_int, P(i64)],
         "gat_params_init": [vp, C.c_uint64],
         "gat_params_set": [vp, C.c_int, vp, i64],
@@ -130,6 +132,7 @@ def _declare(lib: C.CDLL) -> None:
         "gat_head_backward": [vp],
         "gat_layer_backward_edges": [vp, i32],
         "gat_layer_backward_dense": [vp, i32],
+        "gat_layer_exchange": [vp, i32, P(i32)],
         "gat_table": [vp, C.c_int, i32, P(vp), P(i64), P(i64)],
         "gat_bind_table": [vp, C.c_int, i32, vp, i64],
         "gat_tap": [vp, C.c_int, i32, vp, i64],
@@ -244,6 +247,15 @@ class GatContext:
     def set_features_device(self, d_x: int, n_rows: int, in_dim: int):
         _chk(self.lib.gat_set_features_device(self._ctx, C.c_void_p(d_x), n_rows, in_dim))
 
+    def set_source_features(self, x_table):
+        """Replicated layer-0 input: features of every source-table row, [n_table][F0] (instead of
+        set_features; layer 0 then needs no exchange)."""
+        x = np.ascontiguousarray(x_table, np.float32)
+        _chk(self.lib.gat_set_source_features(self._ctx, _np_ptr(x), x.shape[0], x.shape[1]))
+
+    def set_source_features_device(self, d_x: int, n_table: int, in_dim: int):
+        _chk(self.lib.gat_set_source_features_device(self._ctx, C.c_void_p(d_x), n_table, in_dim))
+
     def set_labels(self, labels):
         lab = np.ascontiguousarray(labels, np.int32)
         _chk(self.lib.gat_set_labels(self._ctx, _np_ptr(lab), len(lab)))
@@ -331,6 +343,11 @@ class GatContext:
 
     def layer_backward_dense(self, l: int):
         _chk(self.lib.gat_layer_backward_dense(self._ctx, l))
+
+    def layer_exchange(self, l: int) -> bool:
+        need = C.c_int32(0)
+        _chk(self.lib.gat_layer_exchange(self._ctx, l, C.byref(need)))
+        return bool(need.value)
 
     def table(self, which: int, l: int):
         p, n, w = C.c_void_p(), C.c_int64(), C.c_int64()

@@ -72,6 +72,7 @@ struct gat_ctx {
     bool have_graph = false, have_x = false, have_labels = false, buffers_ready = false;
     int32_t* row_ptr = nullptr; int32_t* col_idx = nullptr; int32_t* labels = nullptr;
     float* X0 = nullptr;
+    float* Xtab = nullptr;                          // [n_table][in_dim] replicated layer-0 input (gat_set_source_features)
     int64_t nW = 0, nA = 0, nWo = 0;
     float* params = nullptr;   // [W | a | Wo]
     float* grads = nullptr;    // [gradW | grada | gradWo]
@@ -223,6 +224,7 @@ static int ensure_buffers(gat_ctx* c) {
     GAT_TRY(dalloc(c, &c->ga_partial, (int64_t)2048 * c->HDmax));      // >= any edge_backward_blocks()
     int64_t gw = 1;
     for (int l = 0; l < L; ++l) gw = std::max(gw, grad_w_scratch_floats(N, c->layers[l].F, c->layers[l].HD));
+    if (c->Xtab) gw = std::max(gw, grad_w_scratch_floats(T, c->layers[0].F, c->layers[0].HD));
     GAT_TRY(dalloc(c, &c->gw_scratch, gw));
     const int C = c->cfg.num_classes, DL = c->layers[L - 1].D;
     GAT_TRY(dalloc(c, &c->hb_partial, (int64_t)head_bwd_blocks(N, C, DL) * C * DL));
@@ -383,6 +385,36 @@ int gat_set_features(gat_ctx* c, const float* x, int64_t n_rows, int32_t in_dim)
 int gat_set_features_device(gat_ctx* c, const float* x, int64_t n_rows, int32_t in_dim) {
     return set_features_common(c, x, n_rows, in_dim, hipMemcpyDeviceToDevice);
 }
+// The layer-0 input is static, so a shard may hold it for EVERY row of the source table instead of
+// exchanging layer-0 projections: PL_0 is then computed locally for the whole table and
+// gradW_left_0 is accumulated from the shard's partial gPL_0 table (the parameter-gradient
+// all-reduce completes the sum) — layer 0 needs neither the all-gather nor the reduce-scatter.
+static int set_source_features_common(gat_ctx* c, const float* x, int64_t n_table, int32_t in_dim, hipMemcpyKind kind) {
+    if (!c || !x) return fail(GAT_E_INVALID, "gat_set_source_features: null argument");
+    if (in_dim != c->cfg.in_dim) return fail(GAT_E_INVALID, "gat_set_source_features: in_dim differs from the config");
+    if (!c->have_graph) return fail(GAT_E_STATE, "gat_set_source_features: set the graph first");
+    if (n_table != c->n_table) return fail(GAT_E_INVALID, "gat_set_source_features: row count differs from the source table");
+    if (c->buffers_ready) return fail(GAT_E_STATE, "gat_set_source_features: call before the features/labels complete the context");
+    if (c->X0) return fail(GAT_E_STATE, "gat_set_source_features: features already set (the table replaces gat_set_features)");
+    GAT_TRY(dalloc(c, &c->Xtab, n_table * in_dim));
+    GAT_HIP(hipMemcpyAsync(c->Xtab, x, (size_t)n_table * in_dim * sizeof(float), kind, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    c->X0 = c->Xtab + c->table_row0 * in_dim;      // the shard's own rows are rows table_row0.. of the table
+    c->have_x = true;
+    return ensure_buffers(c);
+}
+int gat_set_source_features(gat_ctx* c, const float* x, int64_t n_table, int32_t in_dim) {
+    return set_source_features_common(c, x, n_table, in_dim, hipMemcpyHostToDevice);
+}
+int gat_set_source_features_device(gat_ctx* c, const float* x, int64_t n_table, int32_t in_dim) {
+    return set_source_features_common(c, x, n_table, in_dim, hipMemcpyDeviceToDevice);
+}
+int gat_layer_exchange(gat_ctx* c, int32_t l, int32_t* needed) {
+    if (!c || !needed) return fail(GAT_E_INVALID, "null argument");
+    if (l < 0 || l >= c->cfg.num_layers) return fail(GAT_E_INVALID, "layer index out of range");
+    *needed = (c->n_table != c->n_rows) && !(l == 0 && c->Xtab);
+    return 0;
+}
 static int set_labels_common(gat_ctx* c, const int32_t* labels, int64_t n_rows, hipMemcpyKind kind) {
     if (!c || !labels) return fail(GAT_E_INVALID, "gat_set_labels: null argument");
     if (c->have_graph && n_rows != c->n_rows) return fail(GAT_E_INVALID, "Invalid labels length");
@@ -488,7 +520,12 @@ int gat_layer_project(gat_ctx* c, int32_t l) {
     GAT_TRY(check_layer(c, l));
     Layer& y = c->layers[l];
     Scope t(c, GAT_K_PROJECT);
-    return launch_project(Xin_of(c, l), W_of(c, l), y.PL + c->table_row0 * y.HD, y.PR, c->n_rows, y.F, y.HD, c->stream);
+    if (l == 0 && c->Xtab) {      // replicated input: whole PL table from the table rows, PR from the shard's rows
+        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, c->stream));
+        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, c->stream);
+    }
+    return launch_project(Xin_of(c, l), W_of(c, l), y.PL + c->table_row0 * y.HD, y.PR, c->n_rows, y.F, y.HD, kPartBoth,
+                          c->stream);
 }
 
 int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
@@ -577,7 +614,12 @@ int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
     const float* gPL_rows = c->gPL + c->table_row0 * y.HD;
     {
         Scope t(c, GAT_K_GRAD_W);
-        GAT_TRY(launch_grad_w(gPL_rows, c->gPR, Xin_of(c, l), gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, c->stream));
+        if (l == 0 && c->Xtab) {  // partial gPL over the whole table x replicated input; the gradient all-reduce sums shards
+            GAT_TRY(launch_grad_w(c->gPL, nullptr, c->Xtab, gW_of(c, l), c->gw_scratch, c->n_table, y.F, y.HD, kPartLeft, c->stream));
+            GAT_TRY(launch_grad_w(nullptr, c->gPR, c->X0, gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, kPartRight, c->stream));
+        } else {
+            GAT_TRY(launch_grad_w(gPL_rows, c->gPR, Xin_of(c, l), gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, kPartBoth, c->stream));
+        }
     }
     if (l == 0) return 0;                                             // E:1528
     Scope t(c, GAT_K_GRAD_X);
@@ -775,7 +817,7 @@ int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, con
     float *PL, *PR, *alpha, *ms, *zs;
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
     GAT_TRY(t.get(&ms, n * h)); GAT_TRY(t.get(&zs, n * h));
-    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, s));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, s));
     EdgeFwdArgs a{};
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
     a.mstat = ms; a.zstat = zs;
@@ -803,7 +845,7 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
     GAT_TRY(t.get(&gPL, n * HD)); GAT_TRY(t.get(&gPR, n * HD)); GAT_TRY(t.get(&gap, (int64_t)blocks * HD));
     GAT_TRY(t.get(&scr, grad_w_scratch_floats(n, f, HD)));
-    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, s));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, s));
     GAT_TRY(launch_transpose_he_to_eh(d_attn_coeff, alpha, e, h, s));
     GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
     // softmax stats of this layer (the fast-path backward recomputes alpha from them): one
@@ -831,7 +873,7 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     a.part_acc = t.part_acc;
     GAT_TRY(launch_edge_backward(a, s));
     GAT_TRY(launch_reduce_partials_add(gap, a.ga_blocks, HD, d_grad_a, s));
-    GAT_TRY(launch_grad_w(gPL, gPR, d_x, d_grad_w, scr, n, f, HD, s));
+    GAT_TRY(launch_grad_w(gPL, gPR, d_x, d_grad_w, scr, n, f, HD, kPartBoth, s));
     if (d_hpre_prev && d_g_prev) GAT_TRY(launch_grad_x(gPL, gPR, d_w, d_hpre_prev, d_g_prev, n, f, HD, slope, s));
     GAT_HIP(hipStreamSynchronize(s));
     return 0;
@@ -864,10 +906,11 @@ int gat_algorithmic_bytes(gat_ctx* c, double* bytes_step, double* per_kernel) {
     for (int l = 0; l < L; ++l) {
         const Layer& y = c->layers[l];
         const double HD = y.HD, H = y.H, F = y.F, Dout = (l == L - 1) ? y.D : y.HD;
-        k[GAT_K_PROJECT] += b * (N * F + 2 * HD * F + 2 * N * HD);
+        const double NL = (l == 0 && c->Xtab) ? (double)c->n_table : N;     // rows of the W_left half
+        k[GAT_K_PROJECT] += b * (std::max(N, NL) * F + 2 * HD * F + (N + NL) * HD);
         k[GAT_K_EDGE_FWD] += 4 * (N + 1) + 4 * E + b * (E * HD + N * HD + E * H + N * HD + N * Dout);
         k[GAT_K_EDGE_BWD] += 4 * (N + 1) + 4 * E + b * (N * HD + E * HD + N * HD + E * H + E * HD + N * HD);
-        k[GAT_K_GRAD_W] += b * (2 * N * HD + N * F + 2 * HD * F);
+        k[GAT_K_GRAD_W] += b * ((N + NL) * HD + std::max(N, NL) * F + 2 * HD * F);
         if (l > 0) k[GAT_K_GRAD_X] += b * (2 * N * HD + 2 * N * F);
     }
     const double head = 2.0 * 4.0 * N * ((double)c->layers.back().D + 2.0 * c->cfg.num_classes + 2.0);

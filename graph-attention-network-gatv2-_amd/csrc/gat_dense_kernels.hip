@@ -12,10 +12,10 @@ namespace {
 struct MapIdentity {
     __device__ __forceinline__ int64_t operator()(int64_t idx) const { return idx; }
 };
-struct MapGradW {             // idx = c*F + f over [2HD][F]  ->  reference layout [HD][2F]
-    int32_t HD, F;
+struct MapGradW {             // idx = (c-c_base)*F + f over rows c of [2HD][F]  ->  reference layout [HD][2F]
+    int32_t HD, F, c_base;
     __device__ __forceinline__ int64_t operator()(int64_t idx) const {
-        const int32_t c = (int32_t)idx / F, f = (int32_t)idx % F;
+        const int32_t c = c_base + (int32_t)idx / F, f = (int32_t)idx % F;
         return (int64_t)(c % HD) * 2 * F + (c / HD) * F + f;
     }
 };
@@ -266,10 +266,11 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* g, int64_t n, co
 }  // namespace
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
-int launch_reduce_gradw(const float* slabs, int32_t ksplit, int32_t HD, int32_t F, float* gradW, hipStream_t s) {
-    const int64_t width = (int64_t)2 * HD * F;
+int launch_reduce_gradw(const float* slabs, int32_t ksplit, int32_t HD, int32_t F, int32_t c_base, int32_t M,
+                        float* gradW, hipStream_t s) {
+    const int64_t width = (int64_t)M * F;
     hipLaunchKernelGGL((reduce_slabs_kernel<MapGradW>), dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, s, slabs,
-                       ksplit, width, gradW, MapGradW{HD, F});
+                       ksplit, width, gradW, MapGradW{HD, F, c_base});
     GAT_HIP(hipGetLastError());
     return 0;
 }

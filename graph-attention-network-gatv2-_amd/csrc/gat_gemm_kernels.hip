@@ -46,9 +46,10 @@ struct ASrcGcat {                 // A(i,k) = k < HD ? gPL[i][k] : gPR[i][k-HD]
     }
 };
 // ---- B sources (copied to LDS once per block / K chunk) ----------------------------------------------
-struct BSrcProject {              // B(k=f, j): j < HD ? W[j][f] : W[j-HD][F+f]
-    const float* W; int32_t F, HD;
+struct BSrcProject {              // B(k=f, j): jj = j0+j;  jj < HD ? W[jj][f] : W[jj-HD][F+f]
+    const float* W; int32_t F, HD, j0;
     __device__ __forceinline__ float at(int k, int j) const {
+        j += j0;
         return j < HD ? W[(int64_t)j * 2 * F + k] : W[(int64_t)(j - HD) * 2 * F + F + k];
     }
     static constexpr bool kAlongK = true;     // consecutive threads -> consecutive k (W rows are k-contiguous)
@@ -61,12 +62,13 @@ struct BSrcGradX {                // B(k=c, j=f): c < HD ? W[c][f] : W[c-HD][F+f
     static constexpr bool kAlongK = false;
 };
 // ---- epilogues ---------------------------------------------------------------------------------------
-struct EpiProject {               // cols < HD -> PL rows, else PR
+struct EpiProject {               // cols j0+j < HD -> PL rows, else PR
     static constexpr bool kTwoPhase = false;
-    float* PL; float* PR; int32_t HD;
+    float* PL; float* PR; int32_t HD, j0;
     __device__ __forceinline__ float pre(int64_t, int) const { return 0.f; }
     __device__ __forceinline__ void apply(int64_t i, int j, float v, float) const { (*this)(i, j, v); }
     __device__ __forceinline__ void operator()(int64_t i, int j, float v) const {
+        j += j0;
         if (j < HD) PL[i * HD + j] = v; else PR[i * HD + (j - HD)] = v;
     }
 };
@@ -233,13 +235,14 @@ int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gPL, const float* __restrict__ gPR,
                                                     const float* __restrict__ X, float* __restrict__ slabs,
-                                                    int64_t n_rows, int32_t HD, int32_t F, int64_t kchunk) {
+                                                    int64_t n_rows, int32_t HD, int32_t F, int64_t kchunk,
+                                                    int32_t c_base, int32_t M) {
     constexpr int KT = 32, BM = 128, BN = 128;
     __shared__ float As[2][KT][BM];
     __shared__ float Bs[2][KT][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, half = lane >> 5;
-    const int M = 2 * HD;
+    // rows c_base .. c_base+M-1 of the concatenated [gPL | gPR] channel space (both halves, or one)
     const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
     const int64_t kb = (int64_t)blockIdx.z * kchunk;
     const int64_t ke = (kb + kchunk < n_rows) ? kb + kchunk : n_rows;
@@ -261,17 +264,17 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
             ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (node < ke) {
-                const int ci = i0 + c, cj = j0 + c;
+                const int ci = c_base + i0 + c, cj = j0 + c;
                 if constexpr (VEC4) {
-                    if (ci < M) ra[p] = ci < HD ? *reinterpret_cast<const float4*>(gPL + node * HD + ci)
-                                                : *reinterpret_cast<const float4*>(gPR + node * HD + (ci - HD));
+                    if (i0 + c < M) ra[p] = ci < HD ? *reinterpret_cast<const float4*>(gPL + node * HD + ci)
+                                                    : *reinterpret_cast<const float4*>(gPR + node * HD + (ci - HD));
                     if (cj < F) rb[p] = *reinterpret_cast<const float4*>(X + node * F + cj);
                 } else {
                     float t[4], u[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int cc = ci + q, jj = cj + q;
-                        t[q] = cc < M ? (cc < HD ? gPL[node * HD + cc] : gPR[node * HD + (cc - HD)]) : 0.f;
+                        t[q] = (cc - c_base) < M ? (cc < HD ? gPL[node * HD + cc] : gPR[node * HD + (cc - HD)]) : 0.f;
                         u[q] = jj < F ? X[node * F + jj] : 0.f;
                     }
                     ra[p] = make_float4(t[0], t[1], t[2], t[3]);
@@ -327,8 +330,8 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
             }
 }
 
-int64_t grad_w_kchunk(int64_t n_rows, int32_t F, int32_t HD) {
-    const int64_t tiles = ((2 * (int64_t)HD + 127) / 128) * (((int64_t)F + 127) / 128);
+int64_t grad_w_kchunk(int64_t n_rows, int32_t F, int32_t M) {
+    const int64_t tiles = (((int64_t)M + 127) / 128) * (((int64_t)F + 127) / 128);
     // split-K over exactly the blocks that fit at once (64 KiB of LDS per block => 2 per CU)
     int64_t splits = resident_blocks((const void*)gradw_kernel<true>, 0) / tiles;
     if (splits < 1) splits = 1;
@@ -343,12 +346,13 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace
 
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows, int32_t F,
-                   int32_t HD, hipStream_t s) {
+                   int32_t HD, int32_t part, hipStream_t s) {
+    const int32_t j0 = part == kPartRight ? HD : 0;
     ASrcRows as{X, F};
-    BSrcProject bs{W, F, HD};
-    EpiProject ep{PL_rows, PR, HD};
+    BSrcProject bs{W, F, HD, j0};
+    EpiProject ep{PL_rows, PR, HD, j0};
     const bool vec4 = (F % 4 == 0) && aligned16(X);
-    return run_rowgemm(as, bs, ep, n_rows, 2 * HD, F, vec4, s);
+    return run_rowgemm(as, bs, ep, n_rows, part == kPartBoth ? 2 * HD : HD, F, vec4, s);
 }
 
 int launch_grad_x(const float* gPL_rows, const float* gPR, const float* W, const float* hpre_prev,
@@ -361,23 +365,30 @@ int launch_grad_x(const float* gPL_rows, const float* gPR, const float* W, const
 }
 
 int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD) {
-    const int64_t kchunk = grad_w_kchunk(n_rows, F, HD);
-    const int64_t ksplit = (n_rows + kchunk - 1) / kchunk;
-    return (ksplit < 1 ? 1 : ksplit) * 2 * HD * (int64_t)F;
+    int64_t need = 0;
+    for (int32_t M : {2 * HD, HD}) {                 // both halves at once, or one half per launch
+        const int64_t kchunk = grad_w_kchunk(n_rows, F, M);
+        const int64_t ksplit = (n_rows + kchunk - 1) / kchunk;
+        need = std::max<int64_t>(need, (ksplit < 1 ? 1 : ksplit) * M * (int64_t)F);
+    }
+    return need;
 }
 
 int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float* gradW, float* scratch,
-                  int64_t n_rows, int32_t F, int32_t HD, hipStream_t s) {
+                  int64_t n_rows, int32_t F, int32_t HD, int32_t part, hipStream_t s) {
     if (n_rows <= 0) return 0;
-    const int64_t kchunk = grad_w_kchunk(n_rows, F, HD);
+    const int M = part == kPartBoth ? 2 * HD : HD;
+    const int c_base = part == kPartRight ? HD : 0;
+    if (part == kPartLeft) gPR = gPL_rows;           // never dereferenced; keeps the alignment test meaningful
+    if (part == kPartRight) gPL_rows = gPR;
+    const int64_t kchunk = grad_w_kchunk(n_rows, F, M);
     const int64_t ksplit = (n_rows + kchunk - 1) / kchunk;
-    const int M = 2 * HD;
     const dim3 grid((unsigned)((F + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)ksplit);
     const bool vec4 = (F % 4 == 0) && (HD % 4 == 0) && aligned16(X) && aligned16(gPL_rows) && aligned16(gPR);
-    if (vec4) hipLaunchKernelGGL(gradw_kernel<true>, grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk);
-    else hipLaunchKernelGGL(gradw_kernel<false>, grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk);
+    if (vec4) hipLaunchKernelGGL(gradw_kernel<true>, grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M);
+    else hipLaunchKernelGGL(gradw_kernel<false>, grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M);
     GAT_HIP(hipGetLastError());
-    return launch_reduce_gradw(scratch, (int32_t)ksplit, HD, F, gradW, s);
+    return launch_reduce_gradw(scratch, (int32_t)ksplit, HD, F, c_base, M, gradW, s);
 }
 
 }  // namespace gat

@@ -113,8 +113,9 @@ int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* s
 int launch_reduce_partials_add(const float* partial, int32_t nblocks, int64_t width, float* out,
                                hipStream_t s);
 
-// gradW[(c%HD)][(c/HD)*F + f] += sum_z slabs[z][c][f]   (c over 2*HD, fixed order)
-int launch_reduce_gradw(const float* slabs, int32_t ksplit, int32_t HD, int32_t F, float* gradW, hipStream_t s);
+// gradW[(c%HD)][(c/HD)*F + f] += sum_z slabs[z][c - c_base][f]   (c over c_base .. c_base+M-1, fixed order)
+int launch_reduce_gradw(const float* slabs, int32_t ksplit, int32_t HD, int32_t F, int32_t c_base, int32_t M,
+                        float* gradW, hipStream_t s);
 
 // Blocks of a 256-thread kernel that are resident on the whole chip at once (occupancy API incl.
 // dynamic LDS; cached).  Persistent kernels use exactly this grid: a larger one runs a second,
@@ -129,13 +130,16 @@ int launch_transpose_nh_to_hn(const float* src_nh, float* dst_hn, int64_t N, int
 // ---- dense kernels (gat_dense_kernels.hip) -------------------------------------------------------
 // PL[table_row0 + i][j] = sum_f X[i][f] * W[j][f],  PR[i][j] = sum_f X[i][f] * W[j][F+f]
 // W in reference layout [HD][2F].
+// part: both halves in one pass over X, or only the W_left (PL) / W_right (PR) half — the two halves run over
+// different row sets when the layer input is replicated on every shard (gat_set_source_features).
+enum : int32_t { kPartBoth = 0, kPartLeft = 1, kPartRight = 2 };
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows,
-                   int32_t F, int32_t HD, hipStream_t s);
+                   int32_t F, int32_t HD, int32_t part, hipStream_t s);
 // gradW[j][0:F] += sum_n gPL[n][j] X[n][:],  gradW[j][F:2F] += sum_n gPR[n][j] X[n][:]
 // scratch: at least grad_w_scratch_floats(n_rows, F, HD) floats.
 int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);
 int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float* gradW,
-                  float* scratch, int64_t n_rows, int32_t F, int32_t HD, hipStream_t s);
+                  float* scratch, int64_t n_rows, int32_t F, int32_t HD, int32_t part, hipStream_t s);
 // gprev[n][f] = (sum_j gPL[n][j] W[j][f] + gPR[n][j] W[j][F+f]) * LReLU'(hpre_prev[n][f])
 int launch_grad_x(const float* gPL_rows, const float* gPR, const float* W, const float* hpre_prev,
                   float* gprev, int64_t n_rows, int32_t F, int32_t HD, float slope, hipStream_t s);

@@ -9,6 +9,13 @@ data crosses shards, once per layer and direction:
                        -> REDUCE-SCATTER the gPL table                    -> dense backward
     end of backward  : ALL-REDUCE of the packed parameter gradients (+ loss, #correct)
 
+Layer 0 is the exception: its input (the node features) is static, so every rank keeps the
+features of ALL table rows (``ShardPlan.table_features`` / ``set_source_features``), projects the
+whole layer-0 table itself and accumulates gradW_left of layer 0 from its partial gPL table — the
+gradient all-reduce completes that sum.  Both layer-0 exchanges disappear: a 2-layer model moves
+one table per direction and step instead of two (xGMI is the scaling limiter: a [2.45M][64] fp32
+table is 627 MB against ~5 ms of per-rank compute at 8 GPUs).
+
 The reference has no distributed code at all (single process, default stream); this is the build's
 own scaling axis.  Rows are split on ``row_ptr`` so every rank holds ~E/P edges (power-law graphs
 are edge-, not node-balanced).  Rank p's rows are padded to ``max_rows`` so that the exchange
@@ -54,6 +61,15 @@ class ShardPlan:
     def from_table_ids(self, tid: np.ndarray) -> np.ndarray:
         owner = tid // self.max_rows
         return (self.bounds[owner] + tid % self.max_rows).astype(np.int32)
+
+    def table_features(self, x_global: np.ndarray) -> np.ndarray:
+        """Global [n][F] features -> the padded source-table layout [world*max_rows][F]."""
+        x_global = np.asarray(x_global)
+        out = np.zeros((self.n_table, x_global.shape[1]), x_global.dtype)
+        for p in range(self.world):
+            lo, hi = int(self.bounds[p]), int(self.bounds[p + 1])
+            out[p * self.max_rows: p * self.max_rows + (hi - lo)] = x_global[lo:hi]
+        return out
 
 
 def edge_balanced_bounds(row_ptr: np.ndarray, world: int) -> np.ndarray:
@@ -162,13 +178,17 @@ class ShardedGat:
         self.gpl = alloc(plan.n_table * max(self.hd))
         ctx.bind_table(1, 0, self.gpl.data_ptr(), self.gpl.numel() * 4)
         self.grads = alloc(ctx.n_params)          # staging buffer for the gradient all-reduce
+        # layer 0 of a context with replicated input needs no exchange (see module docstring)
+        self.exchange = [bool(ctx.layer_exchange(l)) if hasattr(ctx, "layer_exchange") else True
+                         for l in range(self.L)]
 
     def forward(self):
         """-> (global loss sum, global #correct)"""
         import torch
         for l in range(self.L):
             self.ctx.layer_project(l)
-            self.comm.all_gather_rows(self.pl[l], self.hd[l])
+            if self.exchange[l]:
+                self.comm.all_gather_rows(self.pl[l], self.hd[l])
             self.ctx.layer_forward_edges(l)
         loss, correct = self.ctx.head_forward()
         s = torch.tensor([loss, float(correct)], dtype=torch.float64)
@@ -181,7 +201,8 @@ class ShardedGat:
         self.ctx.head_backward()
         for l in range(self.L - 1, -1, -1):
             self.ctx.layer_backward_edges(l)
-            self.comm.reduce_scatter_rows(self.gpl[: self.plan.n_table * self.hd[l]], self.hd[l])
+            if self.exchange[l]:
+                self.comm.reduce_scatter_rows(self.gpl[: self.plan.n_table * self.hd[l]], self.hd[l])
             self.ctx.layer_backward_dense(l)
         # W/a/Wo gradients: one packed buffer (tens of KB: latency-bound, a single all-reduce)
         self.ctx.grads_export(self.grads.data_ptr(), self.grads.numel())

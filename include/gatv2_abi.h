@@ -80,6 +80,14 @@ int gat_set_graph_device(gat_ctx* ctx, const int32_t* d_row_ptr, const int32_t* 
                          int64_t n_rows, int64_t n_edges, int64_t n_table, int64_t table_row0);
 int gat_set_features_device(gat_ctx* ctx, const float* d_x, int64_t n_rows, int32_t in_dim);
 int gat_set_labels_device(gat_ctx* ctx, const int32_t* d_labels, int64_t n_rows);
+/* Replicated layer-0 input for a shard (call INSTEAD of gat_set_features, after gat_set_graph):
+ * the features of every row of the source table, [n_table][F0] (padding rows: zeros).  The input
+ * features are static (read-only in the reference too, E:1151), so each shard can project the
+ * whole layer-0 table itself and accumulate gradW_left of layer 0 from its partial gPL table;
+ * layer 0 then needs no PL all-gather and no gPL reduce-scatter (gat_layer_exchange reports 0) —
+ * the packed parameter-gradient all-reduce completes the sum over shards. */
+int gat_set_source_features(gat_ctx* ctx, const float* x_table, int64_t n_table, int32_t in_dim);
+int gat_set_source_features_device(gat_ctx* ctx, const float* d_x_table, int64_t n_table, int32_t in_dim);
 
 /* ---- parameters (Xavier init E:186-248; flat layouts E:1242-1258) --------------------------- */
 enum { GAT_PARAM_W = 0, GAT_PARAM_A = 1, GAT_PARAM_WO = 2 };
@@ -115,6 +123,9 @@ int gat_head_forward(gat_ctx* ctx, float* loss_sum, int32_t* n_correct);   /* E:
 int gat_head_backward(gat_ctx* ctx);                        /* E:1468 */
 int gat_layer_backward_edges(gat_ctx* ctx, int32_t layer);  /* E:1489, 1503 + edge parts of 1517, 1533 */
 int gat_layer_backward_dense(gat_ctx* ctx, int32_t layer);  /* dense parts of E:1517, 1533; E:1546 */
+/* *needed = 1 if the host must run the PL all-gather / gPL reduce-scatter for this layer
+ * (0 for a single shard, and for layer 0 of a shard with replicated input). */
+int gat_layer_exchange(gat_ctx* ctx, int32_t layer, int32_t* needed);
 
 /* Exchange buffers.  GAT_TABLE_PL: projected source features, [n_table][H_l*D_l] f32, the
  * context writes rows [table_row0, +n_rows) in gat_layer_project and reads all rows in the edge

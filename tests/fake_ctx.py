@@ -52,6 +52,14 @@ class FakeContext:
     def set_features(self, x):
         self.X0 = np.asarray(x, np.float64)
 
+    def set_source_features(self, x_table):
+        self.Xtab = np.asarray(x_table, np.float64)
+        assert self.Xtab.shape[0] == self.n_table
+        self.X0 = self.Xtab[self.row0:self.row0 + self.n]
+
+    def layer_exchange(self, l):
+        return self.n_table != self.n and not (l == 0 and getattr(self, "Xtab", None) is not None)
+
     def set_labels(self, lab):
         self.labels = np.asarray(lab, np.int64)
 
@@ -97,7 +105,10 @@ class FakeContext:
         W, F, HD = self._Wl(l), self.F[l], self.hd[l]
         X = self._X(l)
         tab = self.tables[(0, l)].reshape(self.n_table, HD)
-        tab[self.row0:self.row0 + self.n] = (X @ W[:, :F].T).astype(np.float32)
+        if l == 0 and getattr(self, "Xtab", None) is not None:
+            tab[:] = (self.Xtab @ W[:, :F].T).astype(np.float32)
+        else:
+            tab[self.row0:self.row0 + self.n] = (X @ W[:, :F].T).astype(np.float32)
         self.PR[l] = X @ W[:, F:].T
 
     def layer_forward_edges(self, l):
@@ -158,7 +169,11 @@ class FakeContext:
         HD, F = self.hd[l], self.F[l]
         gPL = self.tables[(1, l)].reshape(self.n_table, HD)[self.row0:self.row0 + self.n].astype(np.float64)
         X, W = self._X(l), self._Wl(l)
-        gW = np.concatenate([gPL.T @ X, self.gPR.T @ X], axis=1)                    # [HD, 2F]
+        if l == 0 and getattr(self, "Xtab", None) is not None:
+            gl = self.tables[(1, l)].reshape(self.n_table, HD).astype(np.float64).T @ self.Xtab
+        else:
+            gl = gPL.T @ X
+        gW = np.concatenate([gl, self.gPR.T @ X], axis=1)                           # [HD, 2F]
         self.grads[self.w_off[l]:self.w_off[l + 1]] += gW.reshape(-1)
         if l > 0:
             gX = gPL @ W[:, :F] + self.gPR @ W[:, F:]

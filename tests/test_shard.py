@@ -69,7 +69,7 @@ def test_fake_context_matches_oracle_single_rank(pkg, orc):
     assert ok, info
 
 
-def _worker(rank, world, port, outdir, use_gpu):
+def _worker(rank, world, port, outdir, use_gpu, replicate):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -98,11 +98,16 @@ def _worker(rank, world, port, outdir, use_gpu):
             ctx = FakeContext(P["heads"], P["outdims"], P["f"], P["c"])
             alloc = lambda k: torch.zeros(k)
         ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
-        ctx.set_features(P["x"][lo:hi]); ctx.set_labels(P["lab"][lo:hi])
+        if replicate:       # static input held for every table row: layer 0 runs without exchanges
+            ctx.set_source_features(plan.table_features(P["x"]))
+        else:
+            ctx.set_features(P["x"][lo:hi])
+        ctx.set_labels(P["lab"][lo:hi])
         for g, arr in enumerate((W, a, Wo)):
             ctx.params_set(g, arr)
         ctx.zero_grad()
         run = S.ShardedGat(ctx, plan, S.TorchComm(), P["heads"], P["outdims"], alloc=alloc)
+        assert run.exchange == [not replicate] + [True] * (len(P["heads"]) - 1)
         loss, correct = run.forward()
         run.backward()
         grads = run.grads.cpu().numpy()
@@ -111,7 +116,7 @@ def _worker(rank, world, port, outdir, use_gpu):
         dist.destroy_process_group()
 
 
-def _run_world(world, use_gpu, pkg, orc):
+def _run_world(world, use_gpu, pkg, orc, replicate=False):
     import torch.multiprocessing as mp
     P = _problem()
     cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
@@ -120,7 +125,7 @@ def _run_world(world, use_gpu, pkg, orc):
     want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
     port = 29500 + (os.getpid() % 2000) + world
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, d, use_gpu), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, d, use_gpu, replicate), nprocs=world, join=True)
         outs = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
     for o in outs:       # every rank holds the global loss and the all-reduced gradients
         assert abs(float(o["loss"]) - ref.loss_sum_f64) < 1e-4 * P["n"]
@@ -130,12 +135,18 @@ def _run_world(world, use_gpu, pkg, orc):
     assert np.array_equal(outs[0]["grads"], outs[-1]["grads"])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_step_gloo_cpu(pkg, orc, world):
-    _run_world(world, False, pkg, orc)
+@pytest.mark.parametrize("world,replicate", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_step_gloo_cpu(pkg, orc, world, replicate):
+    _run_world(world, False, pkg, orc, replicate)
 
 
 @pytest.mark.gpu
 def test_sharded_step_two_ranks_one_gpu(pkg, orc):
     """The real HIP contexts, sharded 2-way on the single GPU of the box (exchanges via gloo)."""
     _run_world(2, True, pkg, orc)
+
+
+@pytest.mark.gpu
+def test_sharded_step_replicated_input_two_ranks_one_gpu(pkg, orc):
+    """Same, with the layer-0 input replicated (gat_set_source_features): no layer-0 exchanges."""
+    _run_world(2, True, pkg, orc, replicate=True)
