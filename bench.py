@@ -169,8 +169,7 @@ def main():
                 out = ctx.forward()
                 ctx.backward()
             else:
-                out = runner.forward()
-                runner.backward()
+                out = runner.step()
             return out
 
         for _ in range(args.warmup):

@@ -120,6 +120,7 @@ def _declare(lib: C.CDLL) -> None:
         "gat_grads_device": [vp, P(vp), P(i64)],
         "gat_grads_export": [vp, vp, i64],
         "gat_grads_import": [vp, vp, i64],
+        "gat_result_export": [vp, vp],
         "gat_forward": [vp, P(f32), P(i32)],
         "gat_backward": [vp],
         "gat_zero_grad": [vp],
@@ -288,6 +289,9 @@ class GatContext:
 
     def grads_export(self, d_dst: int, count: int):
         _chk(self.lib.gat_grads_export(self._ctx, C.c_void_p(d_dst), count))
+
+    def result_export(self, d_dst3: int):
+        _chk(self.lib.gat_result_export(self._ctx, C.c_void_p(d_dst3)))
 
     def grads_import(self, d_src: int, count: int):
         _chk(self.lib.gat_grads_import(self._ctx, C.c_void_p(d_src), count))

@@ -485,6 +485,11 @@ int gat_grads_export(gat_ctx* c, void* d_dst, int64_t count) {
     GAT_HIP(hipMemcpyAsync(d_dst, c->grads, count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
+int gat_result_export(gat_ctx* c, void* d_dst3) {
+    if (!c || !d_dst3) return fail(GAT_E_INVALID, "null argument");
+    if (!c->buffers_ready) return fail(GAT_E_STATE, "gat_result_export: no forward pass yet");
+    return launch_pack_result(c->loss_out, c->correct_out, (float*)d_dst3, c->stream);
+}
 int gat_grads_import(gat_ctx* c, const void* d_src, int64_t count) {
     if (!c || !d_src) return fail(GAT_E_INVALID, "null argument");
     if (count != c->nW + c->nA + c->nWo) return fail(GAT_E_INVALID, "packed gradient size mismatch");

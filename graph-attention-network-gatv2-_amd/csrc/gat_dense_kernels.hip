@@ -147,6 +147,16 @@ __global__ __launch_bounds__(64) void head_finalize_kernel(const double* __restr
     if (threadIdx.x == 0) { *loss_out = (float)l; *correct_out = c; }
 }
 
+// loss sum and #correct as three floats that survive a float all-reduce exactly: the count is split
+// into 12-bit halves (each half's sum over ranks stays below 2^24 for any realistic world size)
+__global__ void pack_result_kernel(const float* __restrict__ loss, const int32_t* __restrict__ correct,
+                                   float* __restrict__ dst) {
+    if (threadIdx.x == 0) {
+        const int32_t c = *correct;
+        dst[0] = *loss; dst[1] = (float)(c & 4095); dst[2] = (float)(c >> 12);
+    }
+}
+
 // C14 (E:553-608): dz = y - onehot; gradWo += dz^T·H_L; g[n,h,d] = (Wo^T dz)[d]·LReLU'(h_pre)/H.
 // Tile of NB nodes in LDS; grad_Wo as a per-block register partial (thread = one (c,d) entry),
 // g written with a coalesced sweep.
@@ -319,6 +329,11 @@ int launch_head_forward(const HeadArgs& a, hipStream_t s) {
     GAT_HIP(hipGetLastError());
     hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(64), 0, s, a.loss_partial, a.correct_partial, blocks,
                        a.loss_out, a.correct_out);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+int launch_pack_result(const float* loss, const int32_t* correct, float* dst3, hipStream_t s) {
+    hipLaunchKernelGGL(pack_result_kernel, dim3(1), dim3(64), 0, s, loss, correct, dst3);
     GAT_HIP(hipGetLastError());
     return 0;
 }

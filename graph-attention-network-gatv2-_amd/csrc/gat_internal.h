@@ -110,6 +110,7 @@ int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* s
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);
 
 // out[c] += sum_b partial[b][c]   (deterministic: one thread per c, ascending b)
+int launch_pack_result(const float* loss, const int32_t* correct, float* dst3, hipStream_t s);
 int launch_reduce_partials_add(const float* partial, int32_t nblocks, int64_t width, float* out,
                                hipStream_t s);
 

@@ -177,19 +177,32 @@ class ShardedGat:
             self.pl.append(t)
         self.gpl = alloc(plan.n_table * max(self.hd))
         ctx.bind_table(1, 0, self.gpl.data_ptr(), self.gpl.numel() * 4)
-        self.grads = alloc(ctx.n_params)          # staging buffer for the gradient all-reduce
+        # staging buffer of the end-of-step all-reduce: packed gradients + [loss, correct lo, correct hi]
+        self._packed = alloc(ctx.n_params + 3)
+        self.grads = self._packed[: ctx.n_params]
         # layer 0 of a context with replicated input needs no exchange (see module docstring)
         self.exchange = [bool(ctx.layer_exchange(l)) if hasattr(ctx, "layer_exchange") else True
                          for l in range(self.L)]
 
-    def forward(self):
-        """-> (global loss sum, global #correct)"""
-        import torch
+    def _forward_phases(self):
         for l in range(self.L):
             self.ctx.layer_project(l)
             if self.exchange[l]:
                 self.comm.all_gather_rows(self.pl[l], self.hd[l])
             self.ctx.layer_forward_edges(l)
+
+    def _backward_phases(self):
+        self.ctx.head_backward()
+        for l in range(self.L - 1, -1, -1):
+            self.ctx.layer_backward_edges(l)
+            if self.exchange[l]:
+                self.comm.reduce_scatter_rows(self.gpl[: self.plan.n_table * self.hd[l]], self.hd[l])
+            self.ctx.layer_backward_dense(l)
+
+    def forward(self):
+        """-> (global loss sum, global #correct); synchronises to return them (use step() in a loop)."""
+        import torch
+        self._forward_phases()
         loss, correct = self.ctx.head_forward()
         s = torch.tensor([loss, float(correct)], dtype=torch.float64)
         if getattr(self.comm, "native", False):
@@ -198,13 +211,22 @@ class ShardedGat:
         return float(s[0]), int(round(float(s[1])))
 
     def backward(self):
-        self.ctx.head_backward()
-        for l in range(self.L - 1, -1, -1):
-            self.ctx.layer_backward_edges(l)
-            if self.exchange[l]:
-                self.comm.reduce_scatter_rows(self.gpl[: self.plan.n_table * self.hd[l]], self.hd[l])
-            self.ctx.layer_backward_dense(l)
+        self._backward_phases()
         # W/a/Wo gradients: one packed buffer (tens of KB: latency-bound, a single all-reduce)
         self.ctx.grads_export(self.grads.data_ptr(), self.grads.numel())
         self.comm.all_reduce_(self.grads)
         self.ctx.grads_import(self.grads.data_ptr(), self.grads.numel())
+
+    def step(self):
+        """forward + backward with no host synchronisation until the end: loss and #correct ride in
+        the tail of the packed-gradient all-reduce.  -> (global loss sum, global #correct)"""
+        n = self.grads.numel()
+        self._forward_phases()
+        self.ctx.head_forward(want_loss=False)
+        self._backward_phases()
+        self.ctx.grads_export(self._packed.data_ptr(), n)
+        self.ctx.result_export(self._packed.data_ptr() + 4 * n)
+        self.comm.all_reduce_(self._packed)
+        self.ctx.grads_import(self._packed.data_ptr(), n)
+        tail = self._packed[n:].cpu()
+        return float(tail[0]), int(round(float(tail[1]) + 4096.0 * float(tail[2])))

@@ -103,6 +103,11 @@ int gat_grads_device(gat_ctx* ctx, void** d_ptr, int64_t* count);
  * device buffer of `count` floats (the buffer the host all-reduces). */
 int gat_grads_export(gat_ctx* ctx, void* d_dst, int64_t count);
 int gat_grads_import(gat_ctx* ctx, const void* d_src, int64_t count);
+/* Async: the last gat_head_forward's results as three floats at d_dst3 — [loss_sum (E:542),
+ * n_correct & 4095, n_correct >> 12] — so the host can append them to the packed gradients and
+ * sum everything over shards in ONE float all-reduce, with no mid-step device sync
+ * (n_correct = lo + 4096*hi after the sum; exact). */
+int gat_result_export(gat_ctx* ctx, void* d_dst3);
 
 /* ---- the step (world == 1): epoch body E:1374-1557 ------------------------------------------- */
 /* forward over all layers + output head + loss; returns sum loss (E:542) and #correct (E:543). */

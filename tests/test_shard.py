@@ -110,7 +110,12 @@ def _worker(rank, world, port, outdir, use_gpu, replicate):
         assert run.exchange == [not replicate] + [True] * (len(P["heads"]) - 1)
         loss, correct = run.forward()
         run.backward()
-        grads = run.grads.cpu().numpy()
+        grads = run.grads.cpu().numpy().copy()
+        ctx.zero_grad()
+        loss2, correct2 = run.step()          # fused variant: one all-reduce, loss in its tail
+        assert correct2 == correct and abs(loss2 - loss) < 1e-5 * max(1.0, abs(loss))
+        # same values up to the all-reduce's summation order (ring chunking depends on the buffer length)
+        assert np.allclose(run.grads.cpu().numpy(), grads, rtol=1e-5, atol=1e-6 * np.abs(grads).max())
         np.savez(os.path.join(outdir, f"r{rank}.npz"), loss=loss, correct=correct, grads=grads)
     finally:
         dist.destroy_process_group()
