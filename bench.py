@@ -98,6 +98,9 @@ def measured_traffic(args, world, kernel):
 
 def main():
     args = parse()
+    # native libraries (RCCL's version banner) write to fd 1: keep stdout for the one JSON line
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -234,7 +237,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, args.workload, heads, outdims, args.cpu_sample_scale)
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     ctx.close()
     if dist is not None:
         dist.barrier()

@@ -607,7 +607,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     }
     if (store) {
         Scope t(c, GAT_K_GPL_SUM);
-        GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, y.HD, c->stream));
+        GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, c->stream));
     }
     Scope t(c, GAT_K_MISC);
     return launch_reduce_partials_add(c->ga_partial, a.ga_blocks, y.HD, ga_of(c, l), c->stream);

@@ -229,28 +229,30 @@ int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, 
 }
 
 // ---- grad_w: slabs[z][c][f] = sum over the block's nodes of [gPL|gPR][n][c] * X[n][f] ------------------
-// Block tile 128 (c) x 128 (f), 2x2 waves of 64x64; node tiles of 32 staged through two LDS buffers in
-// memory layout ([node][c] and [node][f] are already k-major); global loads of tile t+1 are in flight
-// while tile t is multiplied.
-template <bool VEC4>
+// Block tile BM (c) x 128 (f): WM=2 -> 128 x 128 as 2x2 waves of 64x64 (both halves, 2*HD = 128
+// channels); WM=1 -> 64 x 128 as 1x4 waves of 64x32 (one half, HD = 64 channels: no MFMA spent on
+// padding rows).  Node tiles of 32 staged through two LDS buffers in memory layout ([node][c] and
+// [node][f] are already k-major); global loads of tile t+1 are in flight while tile t is multiplied.
+template <bool VEC4, int WM>
 __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gPL, const float* __restrict__ gPR,
                                                     const float* __restrict__ X, float* __restrict__ slabs,
                                                     int64_t n_rows, int32_t HD, int32_t F, int64_t kchunk,
                                                     int32_t c_base, int32_t M) {
-    constexpr int KT = 32, BM = 128, BN = 128;
+    constexpr int KT = 32, BM = 64 * WM, BN = 128;
+    constexpr int WN = 4 / WM, NY = BN / WN / 32;     // waves along f; 32-col MFMA tiles per wave
     __shared__ float As[2][KT][BM];
     __shared__ float Bs[2][KT][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, half = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, half = lane >> 5;
     // rows c_base .. c_base+M-1 of the concatenated [gPL | gPR] channel space (both halves, or one)
     const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
     const int64_t kb = (int64_t)blockIdx.z * kchunk;
     const int64_t ke = (kb + kchunk < n_rows) ? kb + kchunk : n_rows;
-    v16f acc[2][2];
+    v16f acc[2][NY];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NY; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
             if (node < ke) {
                 const int ci = c_base + i0 + c, cj = j0 + c;
                 if constexpr (VEC4) {
-                    if (i0 + c < M) ra[p] = ci < HD ? *reinterpret_cast<const float4*>(gPL + node * HD + ci)
+                    if (c < BM && i0 + c < M) ra[p] = ci < HD ? *reinterpret_cast<const float4*>(gPL + node * HD + ci)
                                                     : *reinterpret_cast<const float4*>(gPR + node * HD + (ci - HD));
                     if (cj < F) rb[p] = *reinterpret_cast<const float4*>(X + node * F + cj);
                 } else {
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int cc = ci + q, jj = cj + q;
-                        t[q] = (cc - c_base) < M ? (cc < HD ? gPL[node * HD + cc] : gPR[node * HD + (cc - HD)]) : 0.f;
+                        t[q] = (c < BM && (cc - c_base) < M) ? (cc < HD ? gPL[node * HD + cc] : gPR[node * HD + (cc - HD)]) : 0.f;
                         u[q] = jj < F ? X[node * F + jj] : 0.f;
                     }
                     ra[p] = make_float4(t[0], t[1], t[2], t[3]);
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
         for (int p = 0; p < 4; ++p) {
             const int idx = tid + 256 * p;
             const int kk = idx >> 5, c = (idx & 31) * 4;
-            *reinterpret_cast<float4*>(&As[buf][kk][c]) = ra[p];
+            if (c < BM) *reinterpret_cast<float4*>(&As[buf][kk][c]) = ra[p];
             *reinterpret_cast<float4*>(&Bs[buf][kk][c]) = rb[p];
         }
     };
@@ -305,13 +307,14 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
 #pragma unroll 4
         for (int ks = 0; ks < KT / 2; ++ks) {
             const int kk = ks * 2 + half;
-            float a[2], b[2];
+            float a[2], b[NY];
             a[0] = As[buf][kk][wm * 64 + li]; a[1] = As[buf][kk][wm * 64 + 32 + li];
-            b[0] = Bs[buf][kk][wn * 64 + li]; b[1] = Bs[buf][kk][wn * 64 + 32 + li];
+#pragma unroll
+            for (int y = 0; y < NY; ++y) b[y] = Bs[buf][kk][wn * (NY * 32) + y * 32 + li];
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
-                for (int y = 0; y < 2; ++y)
+                for (int y = 0; y < NY; ++y)
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
         }
         if (t + 1 < ntile) store_tile(buf ^ 1);
@@ -321,19 +324,22 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
+        for (int y = 0; y < NY; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int col = j0 + wn * 64 + y * 32 + li;
+                const int col = j0 + wn * (NY * 32) + y * 32 + li;
                 if (row < M && col < F) out[(int64_t)row * F + col] = acc[x][y][r];
             }
 }
 
+inline int grad_w_bm(int32_t M) { return (M % 128 == 0 || M % 128 > 64) ? 128 : 64; }
+
 int64_t grad_w_kchunk(int64_t n_rows, int32_t F, int32_t M) {
-    const int64_t tiles = (((int64_t)M + 127) / 128) * (((int64_t)F + 127) / 128);
-    // split-K over exactly the blocks that fit at once (64 KiB of LDS per block => 2 per CU)
-    int64_t splits = resident_blocks((const void*)gradw_kernel<true>, 0) / tiles;
+    const int bm = grad_w_bm(M);
+    const int64_t tiles = (((int64_t)M + bm - 1) / bm) * (((int64_t)F + 127) / 128);
+    // split-K over exactly the blocks that fit at once (LDS-limited: 64 / 48 KiB per block)
+    int64_t splits = resident_blocks(bm == 128 ? (const void*)gradw_kernel<true, 2> : (const void*)gradw_kernel<true, 1>, 0) / tiles;
     if (splits < 1) splits = 1;
     int64_t kchunk = (n_rows + splits - 1) / splits;
     kchunk = ((kchunk + 31) / 32) * 32;
@@ -383,10 +389,13 @@ int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float
     if (part == kPartRight) gPL_rows = gPR;
     const int64_t kchunk = grad_w_kchunk(n_rows, F, M);
     const int64_t ksplit = (n_rows + kchunk - 1) / kchunk;
-    const dim3 grid((unsigned)((F + 127) / 128), (unsigned)((M + 127) / 128), (unsigned)ksplit);
+    const int bm = grad_w_bm(M);
+    const dim3 grid((unsigned)((F + 127) / 128), (unsigned)((M + bm - 1) / bm), (unsigned)ksplit);
     const bool vec4 = (F % 4 == 0) && (HD % 4 == 0) && aligned16(X) && aligned16(gPL_rows) && aligned16(gPR);
-    if (vec4) hipLaunchKernelGGL(gradw_kernel<true>, grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M);
-    else hipLaunchKernelGGL(gradw_kernel<false>, grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M);
+#define GAT_GRADW(V_, WM_) hipLaunchKernelGGL((gradw_kernel<V_, WM_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M)
+    if (vec4) { if (bm == 128) GAT_GRADW(true, 2); else GAT_GRADW(true, 1); }
+    else { if (bm == 128) GAT_GRADW(false, 2); else GAT_GRADW(false, 1); }
+#undef GAT_GRADW
     GAT_HIP(hipGetLastError());
     return launch_reduce_gradw(scratch, (int32_t)ksplit, HD, F, c_base, M, gradW, s);
 }

@@ -103,8 +103,8 @@ bool edge_fast_path(int32_t H, int32_t D);  // wave-per-row templates cover this
 // ---- source-major slot index + segmented sum (gat_csc.hip) ----------------------------------------
 int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t* pos, int32_t* src_ptr,
               hipStream_t s);
-int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int32_t HD,
-                   hipStream_t s);
+int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
+                   int32_t HD, hipStream_t s);
 
 int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);

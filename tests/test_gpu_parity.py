@@ -1,6 +1,8 @@
 """GPU parity: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same
 seeded inputs.  Tolerances (north_star): CSR->COO bit-exact; attention / h_pre / y / loss 1e-4;
 gradients 1e-4 (fp32 order effects: 1e-3) of the tensor's max-abs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -224,3 +226,44 @@ def test_wide_heads_generic_path(pkg, orc):
         _gclose(ctx.grads_get(A.PARAM_A), ref.grada, "grada")
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("group", ["0", "1"])
+def test_source_hub_both_gpl_sum_variants(pkg, orc, group, monkeypatch):
+    """A source with hundreds of out-edges among short lists: the source-major sum's wave-per-source
+    kernel and its group-per-source variant (shards: ~deg/P slots per source; big lists handed to
+    the whole wave) must both match the oracle."""
+    import subprocess, sys, textwrap
+    # GAT_GPL_GROUP is read once per process: run each variant in its own interpreter
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import __graft_entry__ as entry
+        from conftest import grad_close
+        pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
+        rng = np.random.default_rng(17)
+        n = 240
+        rows = [np.unique(np.concatenate([[3] if i % 4 else [3, 7], rng.integers(0, n, rng.integers(0, 6))])) for i in range(n)]
+        rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+        ci = np.concatenate(rows).astype(np.int32)
+        x = rng.standard_normal((n, 10)).astype(np.float32)
+        lab = rng.integers(0, 5, n).astype(np.int32); lab[0] = 4
+        for heads, outdims in (([8, 8], [8, 8]), ([4, 2], [8, 8]), ([1, 1], [8, 8])):
+            cfg = orc.Config(heads, outdims, 10, 5)
+            W, a, Wo = orc.xavier_params(cfg, 5)
+            ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+            ctx = pkg.GatContext(heads, outdims, 10, 5)
+            ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
+            for g, arr in enumerate((W, a, Wo)): ctx.params_set(g, arr)
+            ctx.zero_grad(); loss, correct = ctx.forward(); ctx.backward()
+            assert abs(loss - ref.loss_sum_f64) / n < 1e-4 and correct == ref.n_correct
+            for grp, want in ((A.PARAM_W, ref.gradW), (A.PARAM_A, ref.grada), (A.PARAM_WO, ref.gradWo)):
+                ok, info = grad_close(ctx.grads_get(grp), want, 1e-3)
+                assert ok, (heads, grp, info)
+            ctx.close()
+        print("OK")
+    """)
+    env = dict(os.environ, GAT_GPL_GROUP=group)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
