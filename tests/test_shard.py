@@ -155,3 +155,76 @@ def test_sharded_step_two_ranks_one_gpu(pkg, orc):
 def test_sharded_step_replicated_input_two_ranks_one_gpu(pkg, orc):
     """Same, with the layer-0 input replicated (gat_set_source_features): no layer-0 exchanges."""
     _run_world(2, True, pkg, orc, replicate=True)
+
+
+def _run_virtual_ranks(world, use_gpu, replicate, pkg, orc):
+    """P ranks as P threads of this process over the loopback comm (P up to 8 on a one-GPU box)."""
+    import threading
+    import torch
+    from loopback import Hub, LoopbackComm
+    P = _problem(n=120, e=900)
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    W, a, Wo = orc.xavier_params(cfg, 11)
+    ref = orc.step(cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo)
+    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    S = pkg.shard
+    hub = Hub(world, sync=(lambda: torch.cuda.synchronize()) if use_gpu else None)
+    results, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            plan = S.make_plan(P["rp"], world, rank)
+            rp_l, ci_l = S.local_csr(plan, P["rp"], P["ci"])
+            lo, hi = plan.row0, plan.row0 + plan.n_rows
+            if use_gpu:
+                torch.cuda.set_device(0)
+                dev = torch.device("cuda", 0)
+                stream = torch.cuda.Stream(device=dev)
+                cm = torch.cuda.stream(stream); cm.__enter__()
+                ctx = pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"], device=0, stream=stream.cuda_stream)
+                alloc = lambda k: torch.zeros(k, dtype=torch.float32, device=dev)
+            else:
+                from fake_ctx import FakeContext
+                ctx = FakeContext(P["heads"], P["outdims"], P["f"], P["c"])
+                alloc = lambda k: torch.zeros(k)
+            ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
+            if replicate:
+                ctx.set_source_features(plan.table_features(P["x"]))
+            else:
+                ctx.set_features(P["x"][lo:hi])
+            ctx.set_labels(P["lab"][lo:hi])
+            for g, arr in enumerate((W, a, Wo)):
+                ctx.params_set(g, arr)
+            ctx.zero_grad()
+            run = S.ShardedGat(ctx, plan, LoopbackComm(hub, rank), P["heads"], P["outdims"], alloc=alloc)
+            loss, correct = run.step()
+            results[rank] = (loss, correct, run.grads.cpu().numpy().copy())
+            if use_gpu:
+                ctx.close()
+        except BaseException as ex:       # noqa: BLE001 - report and release the other threads
+            errors.append((rank, repr(ex)))
+            hub.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for loss, correct, grads in results:
+        assert abs(loss - ref.loss_sum_f64) < 1e-4 * P["n"] and correct == ref.n_correct
+        ok, info = grad_close(grads, want, 1e-3 if use_gpu else 2e-4, frac=0.02)
+        assert ok, info
+        assert np.array_equal(grads, results[0][2])          # fixed-order sums: identical on every rank
+
+
+@pytest.mark.parametrize("world,replicate", [(4, False), (8, True)])
+def test_virtual_ranks_cpu(pkg, orc, world, replicate):
+    _run_virtual_ranks(world, False, replicate, pkg, orc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,replicate", [(4, True), (8, True), (8, False)])
+def test_virtual_ranks_one_gpu(pkg, orc, world, replicate):
+    """P = 4 and 8 shards of the real HIP path on the one GPU of the box, loopback exchanges."""
+    _run_virtual_ranks(world, True, replicate, pkg, orc)
