@@ -50,7 +50,8 @@ TABLE_PL, TABLE_GPL = 0, 1
 (TAP_SRC, TAP_DST, TAP_ALPHA, TAP_HPRE, TAP_HOUT, TAP_Y, TAP_G, TAP_GE, TAP_MAX, TAP_SUM, TAP_PL,
  TAP_PR) = range(12)
 (K_PROJECT, K_EDGE_FWD, K_HEAD_FWD, K_HEAD_BWD, K_EDGE_BWD, K_GPL_SUM, K_GRAD_W, K_GRAD_X, K_MISC,
- K_COUNT) = range(10)
+ K_EXCHANGE, K_COUNT) = range(11)
+COMM_ID_BYTES = 128
 
 _lib: Optional[C.CDLL] = None
 
@@ -121,6 +122,10 @@ def _declare(lib: C.CDLL) -> None:
         "gat_grads_export": [vp, vp, i64],
         "gat_grads_import": [vp, vp, i64],
         "gat_result_export": [vp, vp],
+        "gat_comm_unique_id": [vp],
+        "gat_comm_init_rccl": [vp, i32, i32, vp],
+        "gat_comm_init_host": [vp, i32, i32, C.c_char_p, i64],
+        "gat_step": [vp, P(f32), P(i32)],
         "gat_forward": [vp, P(f32), P(i32)],
         "gat_backward": [vp],
         "gat_zero_grad": [vp],
@@ -311,6 +316,29 @@ class GatContext:
 
     def backward(self):
         _chk(self.lib.gat_backward(self._ctx))
+
+    def step(self, want_loss: bool = True):
+        """forward + backward (with a transport attached: exchanges and the single all-reduce inside)."""
+        if not want_loss:
+            _chk(self.lib.gat_step(self._ctx, None, None))
+            return None
+        loss, corr = C.c_float(), C.c_int32()
+        _chk(self.lib.gat_step(self._ctx, C.byref(loss), C.byref(corr)))
+        return loss.value, corr.value
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _chk(load_library().gat_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rccl(self, world: int, rank: int, unique_id: bytes):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be COMM_ID_BYTES long")
+        _chk(self.lib.gat_comm_init_rccl(self._ctx, world, rank, C.c_char_p(unique_id)))
+
+    def comm_init_host(self, world: int, rank: int, shm_name: str, bytes_per_rank: int):
+        _chk(self.lib.gat_comm_init_host(self._ctx, world, rank, shm_name.encode(), bytes_per_rank))
 
     def zero_grad(self):
         _chk(self.lib.gat_zero_grad(self._ctx))

@@ -75,7 +75,8 @@ struct gat_ctx {
     float* Xtab = nullptr;                          // [n_table][in_dim] replicated layer-0 input (gat_set_source_features)
     int64_t nW = 0, nA = 0, nWo = 0;
     float* params = nullptr;   // [W | a | Wo]
-    float* grads = nullptr;    // [gradW | grada | gradWo]
+    float* grads = nullptr;    // [gradW | grada | gradWo] + 4 floats of tail: [loss, correct lo, correct hi, -]
+    std::unique_ptr<gat::Comm> comm;                // exchange transport of a shard (gat_comm_init_*)
     float* adam_m = nullptr; float* adam_v = nullptr;
     int32_t HDmax = 0, Hmax = 0;
     float* gPL = nullptr; bool gPL_bound = false;   // [n_table][HDmax]
@@ -302,7 +303,7 @@ int gat_create(const gat_config* cfg, gat_ctx** out) {
     gat_ctx* p = c.get();
     const int64_t np = c->nW + c->nA + c->nWo;
     GAT_TRY(dalloc(p, &p->params, np));
-    GAT_TRY(dalloc(p, &p->grads, np));
+    GAT_TRY(dalloc(p, &p->grads, np + 4));
     GAT_TRY(dalloc(p, &p->clip_scratch, 4));
     GAT_HIP(hipMemsetAsync(p->params, 0, np * sizeof(float), p->stream));
     GAT_HIP(hipMemsetAsync(p->grads, 0, np * sizeof(float), p->stream));
@@ -315,6 +316,7 @@ int gat_destroy(gat_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->ev_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    c->comm.reset();
     for (void* p : c->owned) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -632,26 +634,109 @@ int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
                          y.HD, c->cfg.negative_slope, c->stream);
 }
 
-// ---- whole step (single shard) ---------------------------------------------------------------------------------
-int gat_forward(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
+// ---- whole step (single shard, or a shard with a transport attached) ------------------------------------------
+static int64_t table_slice(gat_ctx* c, const Layer& y) { return (c->n_table / c->comm->world) * y.HD; }
+static bool needs_exchange(gat_ctx* c, int l) { return c->n_table != c->n_rows && !(l == 0 && c->Xtab); }
+static int check_step(gat_ctx* c, const char* who) {
     GAT_TRY(check_layer(c, 0));
-    if (c->n_table != c->n_rows)
-        return fail(GAT_E_STATE, "gat_forward: sharded context — drive the phase API with the exchange steps");
+    if (c->n_table != c->n_rows && !c->comm)
+        return fail(GAT_E_STATE, std::string(who) + ": sharded context — attach a transport (gat_comm_init_*) or drive "
+                                                   "the phase API with the exchange steps");
+    return 0;
+}
+static int forward_phases(gat_ctx* c) {
     for (int l = 0; l < c->cfg.num_layers; ++l) {
         GAT_TRY(gat_layer_project(c, l));
+        if (c->comm && needs_exchange(c, l)) {
+            Scope t(c, GAT_K_EXCHANGE);
+            GAT_TRY(c->comm->all_gather(c->layers[l].PL, table_slice(c, c->layers[l]), c->stream));
+        }
         GAT_TRY(gat_layer_forward_edges(c, l));
     }
-    return gat_head_forward(c, loss_sum, n_correct);
+    return 0;
 }
-int gat_backward(gat_ctx* c) {
-    GAT_TRY(check_layer(c, 0));
-    if (c->n_table != c->n_rows)
-        return fail(GAT_E_STATE, "gat_backward: sharded context — drive the phase API with the exchange steps");
+static int backward_phases(gat_ctx* c) {
     GAT_TRY(gat_head_backward(c));
     for (int l = c->cfg.num_layers - 1; l >= 0; --l) {
         GAT_TRY(gat_layer_backward_edges(c, l));
+        if (c->comm && needs_exchange(c, l)) {
+            Scope t(c, GAT_K_EXCHANGE);
+            GAT_TRY(c->comm->reduce_scatter(c->gPL, table_slice(c, c->layers[l]), c->stream));
+        }
         GAT_TRY(gat_layer_backward_dense(c, l));
     }
+    return 0;
+}
+// tail of the packed gradient buffer -> host values (after an all-reduce the sums over shards)
+static int read_result_tail(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
+    float t[3] = {0.f, 0.f, 0.f};
+    GAT_HIP(hipMemcpyAsync(t, c->grads + c->nW + c->nA + c->nWo, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    if (loss_sum) *loss_sum = t[0];
+    if (n_correct) *n_correct = (int32_t)(t[1] + 4096.0f * t[2] + 0.5f);
+    return 0;
+}
+int gat_forward(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
+    GAT_TRY(check_step(c, "gat_forward"));
+    GAT_TRY(forward_phases(c));
+    if (!c->comm) return gat_head_forward(c, loss_sum, n_correct);
+    GAT_TRY(gat_head_forward(c, nullptr, nullptr));
+    if (!loss_sum && !n_correct) return 0;
+    float* tail = c->grads + c->nW + c->nA + c->nWo;
+    GAT_TRY(launch_pack_result(c->loss_out, c->correct_out, tail, c->stream));
+    {
+        Scope t(c, GAT_K_EXCHANGE);
+        GAT_TRY(c->comm->all_reduce(tail, 3, c->stream));
+    }
+    return read_result_tail(c, loss_sum, n_correct);
+}
+int gat_backward(gat_ctx* c) {
+    GAT_TRY(check_step(c, "gat_backward"));
+    GAT_TRY(backward_phases(c));
+    if (c->comm) {
+        Scope t(c, GAT_K_EXCHANGE);
+        GAT_TRY(c->comm->all_reduce(c->grads, c->nW + c->nA + c->nWo, c->stream));
+    }
+    return 0;
+}
+int gat_step(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
+    GAT_TRY(check_step(c, "gat_step"));
+    GAT_TRY(forward_phases(c));
+    GAT_TRY(gat_head_forward(c, nullptr, nullptr));
+    GAT_TRY(backward_phases(c));
+    const int64_t np = c->nW + c->nA + c->nWo;
+    GAT_TRY(launch_pack_result(c->loss_out, c->correct_out, c->grads + np, c->stream));
+    if (c->comm) {
+        Scope t(c, GAT_K_EXCHANGE);
+        GAT_TRY(c->comm->all_reduce(c->grads, np + 3, c->stream));
+    }
+    if (!loss_sum && !n_correct) return 0;
+    return read_result_tail(c, loss_sum, n_correct);
+}
+
+// ---- transports ----------------------------------------------------------------------------------------------
+static int check_comm_target(gat_ctx* c, int32_t world, int32_t rank) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    if (c->comm) return fail(GAT_E_STATE, "a transport is already attached");
+    if (!c->have_graph) return fail(GAT_E_STATE, "gat_comm_init: set the graph first");
+    if (world < 1 || rank < 0 || rank >= world) return fail(GAT_E_INVALID, "gat_comm_init: bad world / rank");
+    if (c->n_table % world != 0 || c->table_row0 != (int64_t)rank * (c->n_table / world) || c->n_rows > c->n_table / world)
+        return fail(GAT_E_INVALID, "gat_comm_init: the source table must be [world][max_rows] with this shard's rows at rank*max_rows");
+    return 0;
+}
+int gat_comm_unique_id(void* id_out) { return comm_unique_id(id_out); }
+int gat_comm_init_rccl(gat_ctx* c, int32_t world, int32_t rank, const void* id) {
+    GAT_TRY(check_comm_target(c, world, rank));
+    Comm* cm = nullptr;
+    GAT_TRY(comm_create_rccl(world, rank, id, &cm));
+    c->comm.reset(cm);
+    return 0;
+}
+int gat_comm_init_host(gat_ctx* c, int32_t world, int32_t rank, const char* shm_name, int64_t bytes_per_rank) {
+    GAT_TRY(check_comm_target(c, world, rank));
+    Comm* cm = nullptr;
+    GAT_TRY(comm_create_host(world, rank, shm_name, bytes_per_rank, &cm));
+    c->comm.reset(cm);
     return 0;
 }
 int gat_zero_grad(gat_ctx* c) {
@@ -886,7 +971,8 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
 
 // ---- measurement -------------------------------------------------------------------------------------------------------
 static const char* kNames[GAT_K_COUNT] = {"project_gemm", "edge_forward", "head_forward", "head_backward",
-                                          "edge_backward", "gpl_sum", "grad_w_gemm", "grad_x_gemm", "misc"};
+                                          "edge_backward", "gpl_sum", "grad_w_gemm", "grad_x_gemm", "misc",
+                                          "exchange"};
 const char* gat_kernel_name(int k) { return (k >= 0 && k < GAT_K_COUNT) ? kNames[k] : "?"; }
 int gat_kernel_stats(gat_ctx* c, int k, int64_t* launches, double* total_ms) {
     if (!c || k < 0 || k >= GAT_K_COUNT) return fail(GAT_E_INVALID, "bad argument");

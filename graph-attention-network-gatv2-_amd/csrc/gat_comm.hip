@@ -1,0 +1,253 @@
+// gat_comm.hip — the three exchanges of a destination-range shard, behind one interface.
+//
+// The reference is a single process on one GPU; sharding is this build's scaling axis.
+// Per layer and direction one table crosses shards — PL rows forward (all-gather), gPL partial sums
+// backward (reduce-scatter) — plus one all-reduce of the packed parameter gradients.  Tables are
+// [world][slice] arrays (shard.py / host/shard_plan.h pad every rank to max_rows), so all three are
+// the fixed-count, in-place forms.
+//
+//   RcclComm : RCCL over xGMI, enqueued on the context's stream.  librccl is dlopen'ed at
+//              gat_comm_init_rccl — single-GPU users of libgatv2_hip.so never load it, and inside a
+//              torch process the copy torch already loaded (same soname) is the one that binds.
+//   HostComm : staged through a POSIX shared-memory segment with a process-shared barrier; sums in
+//              ascending rank order (bitwise identical on every rank).  For tests (several ranks
+//              sharing one GPU, which RCCL refuses) and boxes without peer links.
+#include "gat_internal.h"
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstring>
+#include <memory>
+#include <ctime>
+
+namespace gat {
+
+Comm::~Comm() {}
+
+namespace {
+
+// ---- RCCL (types restated from the public NCCL API; resolved at run time) ------------------------------
+typedef struct ncclComm* ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+static_assert(sizeof(ncclUniqueId) == GAT_COMM_ID_BYTES, "unique id size");
+enum { kNcclSuccess = 0, kNcclFloat32 = 7, kNcclSum = 0 };
+
+struct RcclApi {
+    void* h = nullptr;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+int load_rccl(RcclApi** out) {
+    static RcclApi api;
+    static int state = 0;                                    // 0 = not tried, 1 = ok, -1 = failed
+    static std::string why;
+    if (state == 0) {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.h) break;
+        }
+        if (!api.h) { state = -1; why = std::string("dlopen(librccl): ") + dlerror(); }
+        else {
+            bool ok = true;
+            auto sym = [&](const char* s) { void* p = dlsym(api.h, s); if (!p) { ok = false; why = std::string("librccl lacks ") + s; } return p; };
+            api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+            api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+            api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+            api.ReduceScatter = (decltype(api.ReduceScatter))sym("ncclReduceScatter");
+            api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+            api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+            state = ok ? 1 : -1;
+        }
+    }
+    if (state != 1) return fail(GAT_E_UNSUPPORTED, why);
+    *out = &api;
+    return 0;
+}
+
+#define GAT_NCCL(api, x)                                                                                   \
+    do {                                                                                                   \
+        const int r__ = (x);                                                                               \
+        if (r__ != kNcclSuccess) return fail(GAT_E_COMM, std::string(#x) + ": " + (api)->GetErrorString(r__)); \
+    } while (0)
+
+struct RcclComm final : Comm {
+    RcclApi* api = nullptr;
+    ncclComm_t comm = nullptr;
+    ~RcclComm() override { if (comm) (void)api->CommDestroy(comm); }
+    int all_gather(float* table, int64_t slice, hipStream_t s) override {
+        // in place: sendbuff == recvbuff + rank * sendcount
+        GAT_NCCL(api, api->AllGather(table + (int64_t)rank * slice, table, (size_t)slice, kNcclFloat32, comm, s));
+        return 0;
+    }
+    int reduce_scatter(float* table, int64_t slice, hipStream_t s) override {
+        // in place: recvbuff == sendbuff + rank * recvcount
+        GAT_NCCL(api, api->ReduceScatter(table, table + (int64_t)rank * slice, (size_t)slice, kNcclFloat32, kNcclSum, comm, s));
+        return 0;
+    }
+    int all_reduce(float* buf, int64_t n, hipStream_t s) override {
+        GAT_NCCL(api, api->AllReduce(buf, buf, (size_t)n, kNcclFloat32, kNcclSum, comm, s));
+        return 0;
+    }
+};
+
+// ---- host-staged transport ------------------------------------------------------------------------------
+struct ShmHeader {
+    pthread_barrier_t barrier;
+    int32_t world;
+    int32_t ready;                 // set by rank 0 once the barrier is initialised
+    int64_t bytes_per_rank;
+};
+constexpr size_t kShmHeader = 4096;
+
+struct HostComm final : Comm {
+    std::string name;
+    char* base = nullptr;
+    size_t total = 0;
+    int64_t bytes_per_rank = 0;
+    std::vector<float> tmp;
+    ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
+    float* area(int p) const { return reinterpret_cast<float*>(base + kShmHeader + (size_t)p * bytes_per_rank); }
+    ~HostComm() override {
+        if (base) munmap(base, total);
+        if (rank == 0 && !name.empty()) shm_unlink(name.c_str());
+    }
+    int meet() {
+        const int r = pthread_barrier_wait(&hdr()->barrier);
+        if (r != 0 && r != PTHREAD_BARRIER_SERIAL_THREAD) return fail(GAT_E_COMM, "host transport: barrier failed");
+        return 0;
+    }
+    int fits(int64_t floats) const {
+        if (floats * (int64_t)sizeof(float) > bytes_per_rank)
+            return fail(GAT_E_COMM, "host transport: exchange larger than bytes_per_rank given to gat_comm_init_host");
+        return 0;
+    }
+    int all_gather(float* table, int64_t slice, hipStream_t s) override {
+        GAT_TRY(fits(slice));
+        GAT_HIP(hipMemcpyAsync(area(rank), table + (int64_t)rank * slice, slice * sizeof(float), hipMemcpyDeviceToHost, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        GAT_TRY(meet());
+        for (int p = 0; p < world; ++p)
+            if (p != rank)
+                GAT_HIP(hipMemcpyAsync(table + (int64_t)p * slice, area(p), slice * sizeof(float), hipMemcpyHostToDevice, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        return meet();
+    }
+    int sum_into_tmp(int64_t offset, int64_t n) {
+        tmp.resize((size_t)n);
+        const float* a0 = area(0) + offset;
+        for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = a0[i];
+        for (int p = 1; p < world; ++p) {
+            const float* ap = area(p) + offset;
+            for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] += ap[i];
+        }
+        return 0;
+    }
+    int reduce_scatter(float* table, int64_t slice, hipStream_t s) override {
+        GAT_TRY(fits(slice * world));
+        GAT_HIP(hipMemcpyAsync(area(rank), table, slice * world * sizeof(float), hipMemcpyDeviceToHost, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        GAT_TRY(meet());
+        GAT_TRY(sum_into_tmp((int64_t)rank * slice, slice));
+        GAT_HIP(hipMemcpyAsync(table + (int64_t)rank * slice, tmp.data(), slice * sizeof(float), hipMemcpyHostToDevice, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        return meet();
+    }
+    int all_reduce(float* buf, int64_t n, hipStream_t s) override {
+        GAT_TRY(fits(n));
+        GAT_HIP(hipMemcpyAsync(area(rank), buf, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        GAT_TRY(meet());
+        GAT_TRY(sum_into_tmp(0, n));
+        GAT_HIP(hipMemcpyAsync(buf, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        return meet();
+    }
+};
+
+}  // namespace
+
+int comm_unique_id(void* id_out) {
+    if (!id_out) return fail(GAT_E_INVALID, "null id buffer");
+    RcclApi* api = nullptr;
+    GAT_TRY(load_rccl(&api));
+    ncclUniqueId id;
+    GAT_NCCL(api, api->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int comm_create_rccl(int world, int rank, const void* id_bytes, Comm** out) {
+    if (!id_bytes || !out || world < 1 || rank < 0 || rank >= world) return fail(GAT_E_INVALID, "gat_comm_init_rccl: bad arguments");
+    RcclApi* api = nullptr;
+    GAT_TRY(load_rccl(&api));
+    auto c = std::make_unique<RcclComm>();
+    c->api = api; c->world = world; c->rank = rank;
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof(id));
+    GAT_NCCL(api, api->CommInitRank(&c->comm, world, id, rank));
+    *out = c.release();
+    return 0;
+}
+
+int comm_create_host(int world, int rank, const char* shm_name, int64_t bytes_per_rank, Comm** out) {
+    if (!shm_name || !out || world < 1 || rank < 0 || rank >= world || bytes_per_rank < 16)
+        return fail(GAT_E_INVALID, "gat_comm_init_host: bad arguments");
+    auto c = std::make_unique<HostComm>();
+    c->world = world; c->rank = rank; c->name = shm_name;
+    c->bytes_per_rank = (bytes_per_rank + 4095) & ~(int64_t)4095;
+    c->total = kShmHeader + (size_t)world * c->bytes_per_rank;
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(shm_name);
+        fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return fail(GAT_E_COMM, std::string("shm_open(") + shm_name + "): " + strerror(errno));
+        if (ftruncate(fd, (off_t)c->total) != 0) { close(fd); return fail(GAT_E_COMM, std::string("ftruncate: ") + strerror(errno)); }
+    } else {
+        for (int tries = 0; tries < 3000 && fd < 0; ++tries) {            // rank 0 creates it: wait up to 30 s
+            fd = shm_open(shm_name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < c->total)) { close(fd); fd = -1; }
+            if (fd < 0) { struct timespec ts = {0, 10 * 1000 * 1000}; nanosleep(&ts, nullptr); }
+        }
+        if (fd < 0) return fail(GAT_E_COMM, std::string("host transport: segment ") + shm_name + " did not appear");
+    }
+    void* p = mmap(nullptr, c->total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail(GAT_E_COMM, std::string("mmap: ") + strerror(errno));
+    c->base = (char*)p;
+    ShmHeader* h = c->hdr();
+    if (rank == 0) {
+        pthread_barrierattr_t at;
+        pthread_barrierattr_init(&at);
+        pthread_barrierattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
+        if (pthread_barrier_init(&h->barrier, &at, (unsigned)world) != 0) return fail(GAT_E_COMM, "pthread_barrier_init failed");
+        pthread_barrierattr_destroy(&at);
+        h->world = world; h->bytes_per_rank = c->bytes_per_rank;
+        __atomic_store_n(&h->ready, 1, __ATOMIC_RELEASE);
+    } else {
+        for (int tries = 0; tries < 3000 && !__atomic_load_n(&h->ready, __ATOMIC_ACQUIRE); ++tries) {
+            struct timespec ts = {0, 10 * 1000 * 1000}; nanosleep(&ts, nullptr);
+        }
+        if (!__atomic_load_n(&h->ready, __ATOMIC_ACQUIRE)) return fail(GAT_E_COMM, "host transport: rank 0 never initialised the segment");
+        if (h->world != world || h->bytes_per_rank != c->bytes_per_rank) return fail(GAT_E_COMM, "host transport: ranks disagree on world / bytes_per_rank");
+    }
+    GAT_TRY(c->meet());
+    *out = c.release();
+    return 0;
+}
+
+}  // namespace gat

@@ -27,7 +27,6 @@ namespace gat {
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32

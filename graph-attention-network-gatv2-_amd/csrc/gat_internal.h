@@ -110,6 +110,19 @@ int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* s
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);
 
 // out[c] += sum_b partial[b][c]   (deterministic: one thread per c, ascending b)
+// ---- exchange transports (gat_comm.hip) ---------------------------------------------------------------
+struct Comm {
+    int world = 1, rank = 0;
+    virtual ~Comm();
+    // table: [world][slice] floats; the rank's slice already written / afterwards holding the sum
+    virtual int all_gather(float* table, int64_t slice, hipStream_t s) = 0;
+    virtual int reduce_scatter(float* table, int64_t slice, hipStream_t s) = 0;
+    virtual int all_reduce(float* buf, int64_t n, hipStream_t s) = 0;
+};
+int comm_unique_id(void* id_out);
+int comm_create_rccl(int world, int rank, const void* id_bytes, Comm** out);
+int comm_create_host(int world, int rank, const char* shm_name, int64_t bytes_per_rank, Comm** out);
+
 int launch_pack_result(const float* loss, const int32_t* correct, float* dst3, hipStream_t s);
 int launch_reduce_partials_add(const float* partial, int32_t nblocks, int64_t width, float* out,
                                hipStream_t s);

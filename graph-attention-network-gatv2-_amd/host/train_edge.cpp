@@ -3,12 +3,17 @@
 // stdout/stderr lines, but every device operation goes through the C ABI of include/gatv2_abi.h
 // (libgatv2_hip.so: hand-written HIP for MI355X).  This file is plain host C++: no HIP headers.
 //
-//   ./train_edge --dataset cora --data-root /path/to/datasets --num-layers 2 --heads 8,8 \
+//   ./train_edge --dataset cora --data-root /path/to/datasets --num-layers 2 --heads 8,8 ...
 //                --outdims 8,8 --epochs 20 --optimizer adam --lr 0.01 --clip
 //
 // Additive flags (not in the reference): --seed N (parameter init; default time(NULL) like
 // E:1305), --load-params FILE / --dump-params FILE (raw fp32: W | a | Wo in the reference
-// layouts), --device N, --cache (binary cache of the parsed text files, written next to them).
+// layouts), --device N, --cache (binary cache of the parsed text files, written next to them),
+// --ranks P [--transport rccl|host]: destination-range sharding over P GPUs of the node, one forked
+// process per GPU (devices --device .. --device+P-1), exchanges inside the library (RCCL over xGMI;
+// "host" stages them through shared memory and lets ranks share a GPU — for testing).  Every rank
+// reads the dataset, keeps its destination range (host/shard_plan.h) and the replicated input
+// features; rank 0 prints.  Same numbers as one GPU up to fp32 summation order.
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -22,9 +27,14 @@
 #include <string>
 #include <vector>
 
+#include <signal.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "gatv2_abi.h"
+#include "shard_plan.h"
 
 namespace {
 
@@ -44,6 +54,14 @@ struct Options {
     std::string load_params, dump_params;
     int device = 0;
     bool cache = false;
+    int ranks = 1;
+    std::string transport = "rccl";
+};
+
+struct RankEnv {                      // one forked process per GPU
+    int world = 1, rank = 0;
+    struct Shared { volatile int id_ready; char id[GAT_COMM_ID_BYTES]; }* shared = nullptr;
+    std::string shm_name;
 };
 
 [[noreturn]] void die(const std::string& msg) {
@@ -98,6 +116,13 @@ Options parse_args(int argc, char** argv) {
         else if (a == "--dump-params" && has_val) o.dump_params = argv[++i];
         else if (a == "--device" && has_val) o.device = std::stoi(argv[++i]);
         else if (a == "--cache") o.cache = true;
+        else if (a == "--ranks" && has_val) {
+            o.ranks = std::stoi(argv[++i]);
+            if (o.ranks < 1) die("Error: --ranks must be >= 1\n");
+        } else if (a == "--transport" && has_val) {
+            o.transport = argv[++i];
+            if (o.transport != "rccl" && o.transport != "host") die("Invalid transport choice. Use 'rccl' or 'host'\n");
+        }
     }
     if (o.optimizer == "adam") {
         if (o.beta1 <= 0.0f || o.beta1 >= 1.0f || o.beta2 <= 0.0f || o.beta2 >= 1.0f)
@@ -208,9 +233,7 @@ void check(int rc, const char* what) {
     }
 }
 
-}  // namespace
-
-int main(int argc, char** argv) {
+int run(const Options& o, const RankEnv& env) {
     size_t free_before = 0, total_mem = 0;
     if (gat_mem_info(&free_before, &total_mem) != 0)       // like the reference: report and go on (E:1189-1192)
         std::fprintf(stderr, "Error launching gat_mem_info: %s\n", gat_last_error());
@@ -218,7 +241,6 @@ int main(int argc, char** argv) {
     std::printf("  Total GPU memory: %.2f MB\n", total_mem / (1024.0 * 1024.0));
     std::printf("  Free GPU memory : %.2f MB\n", free_before / (1024.0 * 1024.0));
 
-    const Options o = parse_args(argc, argv);
     const int L = o.layers;
     std::cout << "Configuration:\n"
               << "  Number of layers: " << L << "\n"
@@ -291,14 +313,53 @@ int main(int argc, char** argv) {
     gat_config cfg{};
     cfg.num_layers = L; cfg.heads = o.heads.data(); cfg.outdims = o.outdims.data();
     cfg.in_dim = F0; cfg.num_classes = C; cfg.negative_slope = 0.01f; cfg.device = o.device;
+    int n_devices = 0;
+    check(gat_device_count(&n_devices), "gat_device_count");
+    if (env.world > 1) {
+        if (o.device + env.world <= n_devices) cfg.device = o.device + env.rank;      // one GPU per rank
+        else if (o.transport == "rccl") die("Error: --ranks " + std::to_string(env.world) + " needs that many GPUs from --device on "
+                                            "(RCCL cannot share a GPU between ranks); found " + std::to_string(n_devices) + "\n");
+    }
     gat_ctx* ctx = nullptr;
     check(gat_create(&cfg, &ctx), "gat_create");
-    check(gat_set_graph(ctx, row_ptr.data(), col_idx.data(), N, E, N, 0), "csr_to_coo_kernel");
-    check(gat_set_features(ctx, x.data(), N, F0), "gat_set_features");
-    check(gat_set_labels(ctx, labels.data(), N), "gat_set_labels");
-    check(gat_params_init(ctx, o.seed_given ? o.seed : (uint64_t)time(nullptr)), "xavier_init_kernel");
     int64_t nW = 0, nA = 0, nWo = 0;
     gat_param_count(ctx, GAT_PARAM_W, &nW); gat_param_count(ctx, GAT_PARAM_A, &nA); gat_param_count(ctx, GAT_PARAM_WO, &nWo);
+    if (env.world == 1) {
+        check(gat_set_graph(ctx, row_ptr.data(), col_idx.data(), N, E, N, 0), "csr_to_coo_kernel");
+        check(gat_set_features(ctx, x.data(), N, F0), "gat_set_features");
+        check(gat_set_labels(ctx, labels.data(), N), "gat_set_labels");
+    } else {
+        // this rank's destination range; sources as rows of the padded [world][max_rows] table; the static
+        // input features replicated for every table row (layer 0 then needs no exchange)
+        if (env.world > N) die("Error: more ranks than graph rows\n");
+        const gatshard::Plan plan = gatshard::make_plan(row_ptr.data(), N, env.world, env.rank);
+        std::vector<int32_t> rp_l, ci_l;
+        gatshard::local_csr(plan, row_ptr.data(), col_idx.data(), rp_l, ci_l);
+        check(gat_set_graph(ctx, rp_l.data(), ci_l.data(), plan.n_rows(), (int64_t)ci_l.size(), plan.n_table(), plan.table_row0()),
+              "csr_to_coo_kernel");
+        {
+            const std::vector<float> xt = gatshard::table_features(plan, x.data(), F0);
+            check(gat_set_source_features(ctx, xt.data(), plan.n_table(), F0), "gat_set_source_features");
+        }
+        check(gat_set_labels(ctx, labels.data() + plan.row0(), plan.n_rows()), "gat_set_labels");
+        if (o.transport == "rccl") {
+            if (env.rank == 0) {
+                check(gat_comm_unique_id(env.shared->id), "gat_comm_unique_id");
+                __sync_synchronize();
+                env.shared->id_ready = 1;
+            } else {
+                while (!env.shared->id_ready) usleep(1000);
+                __sync_synchronize();
+            }
+            check(gat_comm_init_rccl(ctx, env.world, env.rank, env.shared->id), "gat_comm_init_rccl");
+        } else {
+            int64_t hd_max = 0;
+            for (int l = 0; l < L; ++l) hd_max = std::max<int64_t>(hd_max, (int64_t)o.heads[l] * o.outdims[l]);
+            const int64_t bytes = std::max<int64_t>(plan.n_table() * hd_max, nW + nA + nWo + 3) * (int64_t)sizeof(float);
+            check(gat_comm_init_host(ctx, env.world, env.rank, env.shm_name.c_str(), bytes), "gat_comm_init_host");
+        }
+    }
+    check(gat_params_init(ctx, o.seed), "xavier_init_kernel");
     if (!o.load_params.empty()) {
         std::vector<float> p(nW + nA + nWo);
         std::ifstream f(o.load_params, std::ios::binary);
@@ -332,7 +393,7 @@ int main(int argc, char** argv) {
         std::cout << " total time: " << elapsed.count() << " ms" << std::endl;
     }
 
-    if (!o.dump_params.empty()) {
+    if (!o.dump_params.empty() && env.rank == 0) {
         std::vector<float> p(nW + nA + nWo);
         check(gat_params_get(ctx, GAT_PARAM_W, p.data(), nW), "gat_params_get");
         check(gat_params_get(ctx, GAT_PARAM_A, p.data() + nW, nA), "gat_params_get");
@@ -342,4 +403,46 @@ int main(int argc, char** argv) {
     }
     gat_destroy(ctx);
     return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Options o = parse_args(argc, argv);
+    if (!o.seed_given) { o.seed = (uint64_t)time(nullptr); o.seed_given = true; }     // E:1305; one seed for all ranks
+    if (o.ranks == 1) return run(o, RankEnv{});
+    // One process per GPU, forked before anything touches the HIP runtime.
+    void* mem = mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (mem == MAP_FAILED) die("Error: mmap failed\n");
+    std::memset(mem, 0, 4096);
+    RankEnv env;
+    env.world = o.ranks;
+    env.shared = static_cast<RankEnv::Shared*>(mem);
+    env.shm_name = "/gatv2_" + std::to_string((long)getpid());
+    std::fflush(nullptr);
+    std::vector<pid_t> kids;
+    for (int r = 0; r < o.ranks; ++r) {
+        const pid_t pid = fork();
+        if (pid < 0) die("Error: fork failed\n");
+        if (pid == 0) {
+            env.rank = r;
+            if (r != 0 && !std::freopen("/dev/null", "w", stdout)) std::_Exit(1);      // rank 0 prints
+            const int rc = run(o, env);
+            std::fflush(nullptr);
+            std::_Exit(rc);
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (size_t left = kids.size(); left > 0; --left) {
+        int status = 0;
+        const pid_t done = wait(&status);
+        if (done < 0) break;
+        const bool ok = WIFEXITED(status) && WEXITSTATUS(status) == 0;
+        if (!ok && rc == 0) {           // a rank failed: the others would wait for it in an exchange
+            rc = 1;
+            for (pid_t k : kids) if (k != done) kill(k, SIGTERM);
+        }
+    }
+    return rc;
 }

@@ -35,7 +35,8 @@ enum {
     GAT_E_INVALID = 10001,   /* bad argument / shape */
     GAT_E_STATE = 10002,     /* call order (e.g. forward before set_graph) */
     GAT_E_NOMEM = 10003,
-    GAT_E_UNSUPPORTED = 10004
+    GAT_E_UNSUPPORTED = 10004,
+    GAT_E_COMM = 10005       /* exchange transport (RCCL / host-staged) */
 };
 
 typedef struct gat_ctx gat_ctx;
@@ -132,6 +133,25 @@ int gat_layer_backward_dense(gat_ctx* ctx, int32_t layer);  /* dense parts of E:
  * (0 for a single shard, and for layer 0 of a shard with replicated input). */
 int gat_layer_exchange(gat_ctx* ctx, int32_t layer, int32_t* needed);
 
+/* ---- exchanges inside the library (optional; the alternative to driving the phases yourself) ----
+ * With a transport attached, gat_forward / gat_backward / gat_step accept a sharded context and run
+ * the exchanges on the context's stream: all-gather of PL / reduce-scatter of gPL for every layer
+ * with gat_layer_exchange() == 1, and one all-reduce of the packed gradients at the end of the
+ * backward.  gat_forward then returns the GLOBAL loss sum and #correct (a 3-float all-reduce), so
+ * every rank prints the same numbers and takes the same optimizer step.
+ *   rccl : RCCL over xGMI; librccl is dlopen'ed here, not at library load.  Rank 0 obtains the id
+ *          (gat_comm_unique_id) and the HOST ships its GAT_COMM_ID_BYTES to the other ranks.
+ *   host : staged through POSIX shared memory `shm_name` (rank 0 creates it); bytes_per_rank >=
+ *          n_table*max(H*D)*4 and >= (n_params+3)*4.  For tests (ranks sharing one GPU) and boxes
+ *          without peer links; sums in ascending rank order. */
+#define GAT_COMM_ID_BYTES 128
+int gat_comm_unique_id(void* id_out);
+int gat_comm_init_rccl(gat_ctx* ctx, int32_t world, int32_t rank, const void* id);
+int gat_comm_init_host(gat_ctx* ctx, int32_t world, int32_t rank, const char* shm_name, int64_t bytes_per_rank);
+/* forward + backward without a host round-trip in between; with a transport the loss and #correct
+ * ride in the tail of the gradient all-reduce.  Returns the global loss sum / #correct. */
+int gat_step(gat_ctx* ctx, float* loss_sum, int32_t* n_correct);
+
 /* Exchange buffers.  GAT_TABLE_PL: projected source features, [n_table][H_l*D_l] f32, the
  * context writes rows [table_row0, +n_rows) in gat_layer_project and reads all rows in the edge
  * phases.  GAT_TABLE_GPL: gradient wrt PL, same shape, the edge backward adds into ALL rows; after
@@ -183,7 +203,8 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
 enum {
     GAT_K_PROJECT = 0, GAT_K_EDGE_FWD = 1, GAT_K_HEAD_FWD = 2, GAT_K_HEAD_BWD = 3,
     GAT_K_EDGE_BWD = 4, GAT_K_GPL_SUM = 5, GAT_K_GRAD_W = 6, GAT_K_GRAD_X = 7, GAT_K_MISC = 8,
-    GAT_K_COUNT = 9
+    GAT_K_EXCHANGE = 9,     /* transport calls of gat_forward / gat_backward / gat_step (event-timed like kernels) */
+    GAT_K_COUNT = 10
 };
 /* Accumulated HIP-event time of kernel class `k` since the last gat_kernel_stats_reset (needs
  * collect_timing=1).  Synchronises the stream. */

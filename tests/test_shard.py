@@ -228,3 +228,81 @@ def test_virtual_ranks_cpu(pkg, orc, world, replicate):
 def test_virtual_ranks_one_gpu(pkg, orc, world, replicate):
     """P = 4 and 8 shards of the real HIP path on the one GPU of the box, loopback exchanges."""
     _run_virtual_ranks(world, True, replicate, pkg, orc)
+
+
+def _comm_worker(rank, world, outdir, shm):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as entry
+    pkg = entry.load_package(); orc = entry.load_oracle()
+    P = _problem()
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    W, a, Wo = orc.xavier_params(cfg, 11)
+    S = pkg.shard
+    plan = S.make_plan(P["rp"], world, rank)
+    rp_l, ci_l = S.local_csr(plan, P["rp"], P["ci"])
+    lo, hi = plan.row0, plan.row0 + plan.n_rows
+    ctx = pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"], device=0)
+    ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
+    ctx.set_source_features(plan.table_features(P["x"]))
+    ctx.set_labels(P["lab"][lo:hi])
+    for g, arr in enumerate((W, a, Wo)):
+        ctx.params_set(g, arr)
+    ctx.comm_init_host(world, rank, shm, 4 * max(plan.n_table * 64, ctx.n_params + 3))
+    ctx.zero_grad()
+    loss, correct = ctx.forward()            # global values: 3-float all-reduce inside
+    ctx.backward()                           # exchanges + gradient all-reduce inside
+    grads = np.concatenate([ctx.grads_get(g) for g in range(3)])
+    ctx.zero_grad()
+    loss2, correct2 = ctx.step()             # fused: one all-reduce
+    grads2 = np.concatenate([ctx.grads_get(g) for g in range(3)])
+    assert correct2 == correct and abs(loss2 - loss) < 1e-5 * max(1.0, abs(loss)) and np.array_equal(grads, grads2)
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), loss=loss, correct=correct, grads=grads)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_library_transport_host_processes_one_gpu(pkg, orc, world):
+    """Exchanges INSIDE the library (gat_comm_init_host + gat_forward/gat_backward/gat_step): `world`
+    processes sharing the box's GPU, no torch.distributed involved."""
+    import torch.multiprocessing as mp
+    P = _problem()
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    W, a, Wo = orc.xavier_params(cfg, 11)
+    ref = orc.step(cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo)
+    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_comm_worker, args=(world, d, f"/gatv2_test_{os.getpid()}_{world}"), nprocs=world, join=True)
+        outs = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
+    for o in outs:
+        assert abs(float(o["loss"]) - ref.loss_sum_f64) < 1e-4 * P["n"] and int(o["correct"]) == ref.n_correct
+        ok, info = grad_close(o["grads"], want, 1e-3, frac=0.02)
+        assert ok, info
+        assert np.array_equal(o["grads"], outs[0]["grads"])
+
+
+@pytest.mark.gpu
+def test_library_transport_rccl_world1(pkg, orc):
+    """RCCL calls themselves (dlopen, communicator, in-place all-gather / reduce-scatter / all-reduce on
+    the context's stream) at world 1 with a padded table, so that every exchange is really issued."""
+    P = _problem()
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    W, a, Wo = orc.xavier_params(cfg, 11)
+    ref = orc.step(cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo)
+    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    n_table = P["n"] + 8                     # one shard, 8 padding rows: n_table != n_rows => exchanges run
+    ctx = pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"], device=0, collect_timing=True)
+    ctx.set_graph(P["rp"], P["ci"], n_table=n_table, table_row0=0)
+    ctx.set_features(P["x"]); ctx.set_labels(P["lab"])
+    for g, arr in enumerate((W, a, Wo)):
+        ctx.params_set(g, arr)
+    ctx.comm_init_rccl(1, 0, pkg.GatContext.comm_unique_id())
+    ctx.zero_grad()
+    loss, correct = ctx.step()
+    grads = np.concatenate([ctx.grads_get(g) for g in range(3)])
+    launches = ctx.kernel_stats()["exchange"][0]
+    ctx.close()
+    assert launches == 2 + 2 + 1             # all-gather and reduce-scatter per layer, one all-reduce
+    assert abs(loss - ref.loss_sum_f64) < 1e-4 * P["n"] and correct == ref.n_correct
+    ok, info = grad_close(grads, want, 1e-3, frac=0.02)
+    assert ok, info

@@ -108,3 +108,42 @@ def test_epochs_match_oracle(pkg, orc, tmp_path, optimizer, clip):
         assert np.abs(final - want).max() < 1e-4
     else:   # Adam's first steps are ~lr*sign(g): an entry whose gradient is ~0 may step the other way
         assert (np.abs(final - want) > 5e-3).mean() < 0.005
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_ranks_match_single_process(pkg, tmp_path, ranks):
+    """train_edge --ranks P: P forked processes, destination-range shards, exchanges inside the library.
+    The box has one GPU, so the ranks share it and the exchanges use the host-staged transport (RCCL
+    refuses two ranks on one device); the sharded epochs must print the same loss/accuracy lines and
+    end at the same parameters as the single-process run (sgd: no sign-flip sensitivity)."""
+    ds = pkg.synth.make_dataset("cora", scale=0.15)
+    pkg.synth.write_text_dataset(ds, str(tmp_path), "tiny")
+    base = ["--dataset", "tiny", "--data-root", str(tmp_path), "--num-layers", "2", "--heads", "8,8", "--outdims", "8,8",
+            "--epochs", "3", "--optimizer", "sgd", "--lr", "0.001", "--seed", "5", "--clip"]
+    one = run(base + ["--dump-params", str(tmp_path / "p1.bin")])
+    assert one.returncode == 0, one.stderr
+    many = run(base + ["--ranks", str(ranks), "--transport", "host", "--dump-params", str(tmp_path / "pN.bin")])
+    assert many.returncode == 0, many.stderr
+    pat = r"Avg Loss: ([0-9.]+), Accuracy: ([0-9.]+)%"
+    a = [(float(m.group(1)), float(m.group(2))) for m in re.finditer(pat, one.stdout)]
+    b = [(float(m.group(1)), float(m.group(2))) for m in re.finditer(pat, many.stdout)]
+    assert len(a) == 3 and len(b) == 3                       # rank 0 prints, the others are silent
+    for (la, aa), (lb, ab) in zip(a, b):
+        assert abs(la - lb) < 1e-4 and abs(aa - ab) < 0.011
+    assert many.stdout.count("Graph loaded:") == 1 and many.stdout.count(" total time: ") == 3
+    p1 = np.fromfile(tmp_path / "p1.bin", dtype=np.float32)
+    pN = np.fromfile(tmp_path / "pN.bin", dtype=np.float32)
+    assert p1.shape == pN.shape and np.abs(p1 - pN).max() < 1e-4 * max(1.0, np.abs(p1).max())
+
+
+@pytest.mark.gpu
+def test_rccl_transport_needs_one_gpu_per_rank(pkg, tmp_path):
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has several GPUs")
+    ds = pkg.synth.make_dataset("cora", scale=0.05)
+    pkg.synth.write_text_dataset(ds, str(tmp_path), "tiny")
+    r = run(["--dataset", "tiny", "--data-root", str(tmp_path), "--num-layers", "2", "--heads", "8,8", "--outdims", "8,8",
+             "--epochs", "1", "--ranks", "2"])
+    assert r.returncode == 1 and "needs that many GPUs" in r.stderr
