@@ -48,6 +48,10 @@ def parse():
                     help="N>1: do not replicate the input features; all-gather / reduce-scatter layer 0 too (A/B)")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0 = auto (~15 s of CPU work)")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--comm", choices=["native", "torch"], default="native",
+                    help="N>1 exchanges: 'native' = RCCL called by the library on the context's stream (in-place "
+                         "all-gather / reduce-scatter, one all-reduce); 'torch' = the same plan driven from "
+                         "shard.ShardedGat over torch.distributed")
     ap.add_argument("--beta", type=float, default=0.75, help="power-law exponent of the degree law (debug)")
     return ap.parse_args()
 
@@ -159,9 +163,18 @@ def main():
             else:                        # static input replicated on every rank: layer 0 runs without exchanges
                 ctx.set_source_features(plan.table_features(pkg.synth.features(n, f, kind=kind)))
             ctx.set_labels(pkg.synth.labels(n, c, rows=(lo, hi)))
-            comm = S.TorchComm()
-            runner = S.ShardedGat(ctx, plan, comm, heads, outdims,
-                                  alloc=lambda k: torch.empty(k, dtype=torch.float32, device=dev))
+            comm_kind = args.comm if args.backend == "nccl" else "torch"
+            if comm_kind == "native":
+                # the library's own RCCL communicator; torch.distributed only ships the 128-byte id
+                idt = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(pkg.GatContext.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                ctx.comm_init_rccl(world, rank, bytes(idt.cpu().tolist()))
+                runner = ctx
+            else:
+                runner = S.ShardedGat(ctx, plan, S.TorchComm(), heads, outdims,
+                                      alloc=lambda k: torch.empty(k, dtype=torch.float32, device=dev))
         del row_ptr, col_idx
         ctx.params_init(42)
         ctx.zero_grad()
@@ -208,7 +221,7 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        dom = max((k for k in stats if stats[k][0] > 0 and k != "misc"), key=lambda k: stats[k][1])
+        dom = max((k for k in stats if stats[k][0] > 0 and k not in ("misc", "exchange")), key=lambda k: stats[k][1])
         launches, tot_ms = stats[dom]
         per_launch_bytes = bytes_k[dom] * args.steps / launches
         avg_ms = tot_ms / launches
@@ -223,8 +236,8 @@ def main():
                 "workload": f"{args.workload}-shape synthetic power-law graph, {n} nodes / {e} edges / {f} feat / "
                             f"{c} classes, {len(heads)}-layer GATv2 heads {heads} outdims {outdims}, fp32",
                 "parallelism": (f"dst-range x{world}, " + ("all layers exchanged" if args.exchange_layer0 else
-                                "input features replicated (layer 0 exchange-free)")) if runner is not None
-                               else "single GPU",
+                                "input features replicated (layer 0 exchange-free)") + f", exchanges: {comm_kind}")
+                               if runner is not None else "single GPU",
                 "loss_per_node": loss / n, "setup_s": round(t_gen, 1), "upload_and_index_s": round(t_up, 2),
             },
             "step_roofline": {"algorithmic_GB_per_step": bytes_step_all / 1e9,
