@@ -182,7 +182,7 @@ static int ensure_buffers(gat_ctx* c) {
         GAT_TRY(dalloc(c, &y.PR, N * y.HD));
         // attn_coeff [E][H] is only materialised for parity taps and for layers on the generic
         // path; the fast path's backward recomputes it from the per-(row, head) softmax stats.
-        if (c->cfg.keep_taps || !edge_fast_path(y.H, y.D)) GAT_TRY(dalloc(c, &y.alpha, E * y.H));
+        if (c->cfg.keep_taps || !edge_fast_path(y.H, y.D, c->n_table)) GAT_TRY(dalloc(c, &y.alpha, E * y.H));
         GAT_TRY(dalloc(c, &y.hpre, N * y.HD));
         GAT_TRY(dalloc(c, &y.hout, N * (l == L - 1 ? y.D : y.HD)));
         GAT_TRY(dalloc(c, &y.g, N * y.HD));
@@ -208,7 +208,7 @@ static int ensure_buffers(gat_ctx* c) {
     // slot index and an [E][H*D] scratch.  GAT_BWD_ATOMICS=1 forces the float-atomic variant (A/B).
     int32_t msg_hd = 0;
     for (int l = 0; l < L; ++l)
-        if (edge_fast_path(c->layers[l].H, c->layers[l].D)) msg_hd = std::max(msg_hd, c->layers[l].HD);
+        if (edge_fast_path(c->layers[l].H, c->layers[l].D, c->n_table)) msg_hd = std::max(msg_hd, c->layers[l].HD);
     const char* force = getenv("GAT_BWD_ATOMICS");
     if (msg_hd > 0 && E > 0 && !(force && force[0] == '1')) {
         float* m = nullptr;
@@ -541,7 +541,7 @@ int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
     EdgeFwdArgs a{};
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
     a.alpha = y.alpha; a.hpre = y.hpre; a.hout = y.hout; a.mstat = y.mstat; a.zstat = y.zstat;
-    a.n_rows = c->n_rows; a.H = y.H; a.D = y.D; a.is_last = (l == c->cfg.num_layers - 1);
+    a.n_rows = c->n_rows; a.n_table = c->n_table; a.H = y.H; a.D = y.D; a.is_last = (l == c->cfg.num_layers - 1);
     a.slope = c->cfg.negative_slope;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
     a.part_acc = c->part_acc; a.part_mz = c->part_mz;
@@ -586,7 +586,7 @@ int gat_head_backward(gat_ctx* c) {
 int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     GAT_TRY(check_layer(c, l));
     Layer& y = c->layers[l];
-    const bool store = c->msg != nullptr && edge_fast_path(y.H, y.D);
+    const bool store = c->msg != nullptr && edge_fast_path(y.H, y.D, c->n_table);
     if (!store) {
         Scope t(c, GAT_K_MISC);
         GAT_HIP(hipMemsetAsync(c->gPL, 0, (size_t)c->n_table * y.HD * sizeof(float), c->stream));
@@ -599,8 +599,8 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
     a.part_acc = c->part_acc;
     a.dbg = c->dbg;
-    a.ga_partial = c->ga_partial; a.n_rows = c->n_rows; a.H = y.H; a.D = y.D;
-    a.ga_blocks = edge_fast_path(y.H, y.D) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr)
+    a.ga_partial = c->ga_partial; a.n_rows = c->n_rows; a.n_table = c->n_table; a.H = y.H; a.D = y.D;
+    a.ga_blocks = edge_fast_path(y.H, y.D, c->n_table) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr)
                                            : edge_backward_blocks(c->n_rows * 4, y.H, y.D, false, false);
     a.slope = c->cfg.negative_slope;
     {
@@ -841,7 +841,7 @@ int gat_tap(gat_ctx* c, int tensor, int32_t l, void* host, int64_t count) {
         case GAT_TAP_MAX: {
             GAT_TRY(need(N * y.H));
             GAT_TRY(transposed(y.mstat, N, y.H, false));
-            if (edge_fast_path(y.H, y.D)) {          // kept in the log2 domain on the device
+            if (edge_fast_path(y.H, y.D, c->n_table)) {          // kept in the log2 domain on the device
                 float* f = static_cast<float*>(host);
                 for (int64_t i = 0; i < N * y.H; ++i) f[i] = std::max(f[i] * 0.6931471805599453f, -1e9f);
             }
@@ -911,7 +911,7 @@ int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, con
     EdgeFwdArgs a{};
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
     a.mstat = ms; a.zstat = zs;
-    a.hpre = d_hpre; a.hout = d_hout; a.n_rows = n; a.H = h; a.D = d; a.is_last = is_last; a.slope = slope;
+    a.hpre = d_hpre; a.hout = d_hout; a.n_rows = n; a.n_table = n; a.H = h; a.D = d; a.is_last = is_last; a.slope = slope;
     GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
     a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots;
     a.part_acc = t.part_acc; a.part_mz = t.part_mz;
@@ -945,8 +945,8 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     {
         EdgeFwdArgs fa{};
         fa.row_ptr = d_row_ptr; fa.col_idx = d_col_idx; fa.PL = PL; fa.PR = PR; fa.a = d_a;
-        fa.alpha = edge_fast_path(h, d) ? nullptr : alpha; fa.hpre = hp_tmp; fa.hout = ho_tmp; fa.mstat = ms; fa.zstat = zs;
-        fa.n_rows = n; fa.H = h; fa.D = d; fa.is_last = 0; fa.slope = slope;
+        fa.alpha = edge_fast_path(h, d, n) ? nullptr : alpha; fa.hpre = hp_tmp; fa.hout = ho_tmp; fa.mstat = ms; fa.zstat = zs;
+        fa.n_rows = n; fa.n_table = n; fa.H = h; fa.D = d; fa.is_last = 0; fa.slope = slope;
         fa.items = t.items; fa.n_items = t.w.n_items; fa.slot_info = t.slot_info; fa.n_slots = t.w.n_slots;
         fa.part_acc = t.part_acc; fa.part_mz = t.part_mz;
         GAT_TRY(launch_edge_forward(fa, s));
@@ -956,9 +956,9 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     a.mstat = ms; a.zstat = zs;
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
     a.hpre = d_hpre; a.g = d_g; a.gPL = gPL; a.gPR = gPR; a.ge = nullptr; a.ga_partial = gap;
-    a.ga_blocks = edge_fast_path(h, d) ? edge_backward_blocks(t.w.n_items, h, d, false, false)
+    a.ga_blocks = edge_fast_path(h, d, n) ? edge_backward_blocks(t.w.n_items, h, d, false, false)
                                        : edge_backward_blocks(n * 4, h, d, false, false);
-    a.n_rows = n; a.H = h; a.D = d; a.slope = slope;
+    a.n_rows = n; a.n_table = n; a.H = h; a.D = d; a.slope = slope;
     a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots;
     a.part_acc = t.part_acc;
     GAT_TRY(launch_edge_backward(a, s));

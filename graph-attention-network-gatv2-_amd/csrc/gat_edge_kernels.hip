@@ -170,6 +170,29 @@ __device__ __forceinline__ int per_lane(int x) {
     return x;
 }
 
+// PL[row][c] with the address as uniform base + 32-bit byte offset: one v_lshl_add_u32 per gather and
+// the `global_load_dword v, voff, s[base]` form, instead of a sign-extension and two 64-bit VALU ops.
+// Valid while the table is < 4 GiB (n_table * H*D * 4; checked by the launchers).
+template <int HD>
+__device__ __forceinline__ float gather_row(const float* __restrict__ table, int row, int c) {
+    const uint32_t off = (uint32_t)row * (uint32_t)(HD * 4) + (uint32_t)c * 4u;
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + off);
+}
+// msg[slot][c] = v.  The message array is E*H*D*4 bytes (15.8 GB on the benchmark graph): 64-bit row
+// base.  When the whole wave works on one edge the slot is wave-uniform: row base on the SALU,
+// lane offset in a VGPR (`global_store_dword voff, v, s[base]`), no VALU address math.
+template <int HD, bool UNIFORM>
+__device__ __forceinline__ void store_row(float* __restrict__ msg, int slot, int c, float v) {
+    if constexpr (UNIFORM) {
+        char* rowb = reinterpret_cast<char*>(msg) + ((int64_t)__builtin_amdgcn_readfirstlane(slot) * (HD * 4));
+        // the lane offset must reach instruction selection as an opaque zext(i32) next to the scalar base: a
+        // visible c*4 is re-associated into (msg + c*4) + slot*row, i.e. a 64-bit VALU add per store
+        *reinterpret_cast<float*>(rowb + (uint32_t)per_lane(c * 4)) = v;
+    } else {
+        (msg + (int64_t)slot * HD)[(unsigned)c] = v;
+    }
+}
+
 // One chunk of UU slots per edge group: UU independent gathers issued back to back (indices
 // clamped into the item, so loads need no predicate), then scores, then the online-softmax update.
 template <int HD, int D, int UU, int USC, bool ALPHA>
@@ -183,8 +206,7 @@ __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_en
     for (int u = 0; u < UU; ++u) {
         const int j = e0 + u * G + gidx;
         const int jc = j < e_end ? j : e_end - 1;
-        const float* prow = A.PL + (int64_t)A.col_idx[jc] * HD;      // wave-uniform when G == 1
-        v[u] = prow[(unsigned)c];
+        v[u] = gather_row<HD>(A.PL, A.col_idx[jc], c);
     }
     // scores: the cross-lane stages run slot-interleaved (UU independent DPP chains), so that no
     // stage waits on the VALU->DPP hazard of its own predecessor
@@ -344,8 +366,7 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
         const int j = e0 + u * G + gidx;
         const int jc = j < e_end ? j : e_end - 1;                // clamped: loads need no predicate
         const int src = A.col_idx[jc];
-        const float* prow = A.PL + (int64_t)src * HD;            // wave-uniform when G == 1
-        v[u] = prow[(unsigned)c];
+        v[u] = gather_row<HD>(A.PL, src, c);
         if constexpr (STORE) sid[u] = (DBG == 2) ? jc : A.pos[jc]; else sid[u] = src;
     }
     // Compute in passes of P <= 8 slots (bounds the live registers; the first pass starts as soon as
@@ -375,7 +396,7 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
             gpr += gs;
             const float msg = fmaf(g, al[q], gs);                // d/dPL[src] from this edge
             if (valid && DBG != 1) {
-                if constexpr (STORE) (A.msg + (int64_t)sid[u] * HD)[(unsigned)c] = msg;
+                if constexpr (STORE) store_row<HD, G == 1>(A.msg, sid[u], c, msg);
                 else unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, msg);
             }
             if constexpr (TAPS) {
@@ -657,7 +678,7 @@ constexpr int kGenericBlocks = 4096;
 int launch_edge_forward(const EdgeFwdArgs& a, hipStream_t s) {
     if (a.n_rows <= 0) return 0;
     const int HD = a.H * a.D, D = a.D;
-    GAT_DISPATCH_HD_D(run_fwd, a, s)
+    if (edge_fast_path(a.H, a.D, a.n_table)) { GAT_DISPATCH_HD_D(run_fwd, a, s) }
     const int64_t blocks = a.n_rows < kGenericBlocks * 8 ? a.n_rows : kGenericBlocks * 8;
     hipLaunchKernelGGL(edge_fwd_generic, dim3((unsigned)blocks), dim3(64), (size_t)HD * sizeof(float), s, a);
     GAT_HIP(hipGetLastError());
@@ -681,8 +702,9 @@ static int fast_probe(const int&, hipStream_t) { return 1; }
 template <int HD, int D>
 int fast_probe_t(const int& x, hipStream_t s) { return fast_probe(x, s); }
 
-bool edge_fast_path(int32_t H, int32_t D_) {
+bool edge_fast_path(int32_t H, int32_t D_, int64_t n_table) {
     const int HD = H * D_, D = D_;
+    if (n_table * HD * (int64_t)sizeof(float) >= ((int64_t)1 << 32)) return false;
     const int dummy = 0;
     auto probe = [&]() -> int {
         GAT_DISPATCH_HD_D(fast_probe_t, dummy, nullptr)
@@ -694,7 +716,7 @@ bool edge_fast_path(int32_t H, int32_t D_) {
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s) {
     const int HD = a.H * a.D, D = a.D;
     if (a.ga_blocks < 1) return fail(GAT_E_INVALID, "edge_backward: ga_blocks must come from edge_backward_blocks()");
-    GAT_DISPATCH_HD_D(run_bwd, a, s)
+    if (edge_fast_path(a.H, a.D, a.n_table)) { GAT_DISPATCH_HD_D(run_bwd, a, s) }
     if (a.pos != nullptr) return fail(GAT_E_INVALID, "edge_backward: the generic path has no store mode");
     const size_t lds = (size_t)(3 * a.H + 2 * HD) * sizeof(float);
     if (lds > 64 * 1024) return fail(GAT_E_UNSUPPORTED, "edge_backward: H*D too large for the generic path");

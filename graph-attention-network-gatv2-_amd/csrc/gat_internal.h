@@ -42,6 +42,7 @@ struct EdgeFwdArgs {
     float* mstat;             // [n_rows][H] softmax max per (row, head); fast path: log2 domain
     float* zstat;             // [n_rows][H] softmax sum
     int64_t n_rows;
+    int64_t n_table;          // rows of the gathered PL table (fast path: < 4 GiB, see edge_fast_path)
     int32_t H, D;
     int32_t is_last;
     float slope;
@@ -86,6 +87,7 @@ struct EdgeBwdArgs {
     float* ga_partial;        // [ga_blocks][HD] written
     int32_t ga_blocks;        // grid size the launcher must use (== rows of ga_partial)
     int64_t n_rows;
+    int64_t n_table;          // rows of the gathered PL table (fast path: < 4 GiB, see edge_fast_path)
     int32_t H, D;
     float slope;
     const int4* items;        // as in EdgeFwdArgs
@@ -98,7 +100,9 @@ struct EdgeBwdArgs {
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s);
 // Grid size (== rows of ga_partial) for the backward of an (H, D) layer over n_items work items.
 int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D, bool store, bool taps);
-bool edge_fast_path(int32_t H, int32_t D);  // wave-per-row templates cover this (H, D)
+// wave-per-row templates cover this (H, D), and the gathered table is < 4 GiB (they address it as
+// uniform base + 32-bit byte offset); anything else runs the generic kernels
+bool edge_fast_path(int32_t H, int32_t D, int64_t n_table);
 
 // ---- source-major slot index + segmented sum (gat_csc.hip) ----------------------------------------
 int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t* pos, int32_t* src_ptr,
