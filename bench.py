@@ -33,6 +33,7 @@ PRESETS = {   # workload -> (heads, outdims); BASELINE.json gives layer/head cou
     "pubmed": ([8, 8], [8, 8]),
     "cora": ([8, 8], [8, 8]),
     "arxiv": ([8, 8, 8], [8, 8, 8]),
+    "pl10m": ([4, 4], [8, 8]),          # BASELINE config 5 (10 M nodes / 250 M edges, 4 heads; run with --dtype bf16)
 }
 
 
@@ -48,6 +49,9 @@ def parse():
                     help="N>1: do not replicate the input features; all-gather / reduce-scatter layer 0 too (A/B)")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0 = auto (~15 s of CPU work)")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of the gathered / exchanged PL table and the message rows (BASELINE config 5 "
+                         "is bf16); arithmetic is fp32 either way.  The headline metric is f32.")
     ap.add_argument("--comm", choices=["native", "torch"], default="native",
                     help="N>1 exchanges: 'native' = RCCL called by the library on the context's stream (in-place "
                          "all-gather / reduce-scatter, one all-reduce); 'torch' = the same plan driven from "
@@ -135,7 +139,8 @@ def main():
     row_ptr, col_idx = pkg.synth.powerlaw_graph(n, e, beta=args.beta)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        ctx = pkg.GatContext(heads, outdims, f, c, device=local_rank, stream=stream.cuda_stream, collect_timing=True)
+        ctx = pkg.GatContext(heads, outdims, f, c, device=local_rank, stream=stream.cuda_stream, collect_timing=True,
+                             dtype=args.dtype)
         force_sharded = os.environ.get("GAT_FORCE_SHARDED") == "1"     # rehearse the N>1 code path on one GPU
         if world == 1 and force_sharded:
             import torch.distributed as dist
@@ -231,7 +236,8 @@ def main():
                       f"edges/sec (fwd+bwd, {len(heads)}-layer 8-head GATv2)",
             "value": e / (dt / args.steps), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "f32 arithmetic, bf16 PL/message storage",
+            "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}-shape synthetic power-law graph, {n} nodes / {e} edges / {f} feat / "
                             f"{c} classes, {len(heads)}-layer GATv2 heads {heads} outdims {outdims}, fp32",

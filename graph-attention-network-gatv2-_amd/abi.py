@@ -41,6 +41,7 @@ class _Config(C.Structure):
         ("flat_lrelu_index", C.c_int32),
         ("collect_timing", C.c_int32),
         ("keep_taps", C.c_int32),
+        ("storage_dtype", C.c_int32),
     ]
 
 
@@ -181,7 +182,8 @@ class GatContext:
 
     def __init__(self, heads: Sequence[int], outdims: Sequence[int], in_dim: int, num_classes: int, *,
                  device: int = 0, stream: int = 0, negative_slope: float = 0.01,
-                 flat_lrelu_index: bool = False, collect_timing: bool = False, keep_taps: bool = False):
+                 flat_lrelu_index: bool = False, collect_timing: bool = False, keep_taps: bool = False,
+                 dtype: str = "f32"):
         if len(heads) != len(outdims) or len(heads) == 0:
             raise ValueError("--heads and --outdims must both have num_layers values")
         self.lib = load_library()
@@ -190,7 +192,9 @@ class GatContext:
         self._h = (C.c_int32 * self.L)(*self.heads)
         self._d = (C.c_int32 * self.L)(*self.outdims)
         cfg = _Config(self.L, self._h, self._d, self.in_dim, self.C, negative_slope, device,
-                      C.c_void_p(stream or None), int(flat_lrelu_index), int(collect_timing), int(keep_taps))
+                      C.c_void_p(stream or None), int(flat_lrelu_index), int(collect_timing), int(keep_taps),
+                      {"f32": 0, "bf16": 1}[dtype])
+        self.storage_bytes = 2 if dtype == "bf16" else 4        # element size of the PL exchange table
         self._ctx = C.c_void_p()
         _chk(self.lib.gat_create(C.byref(cfg), C.byref(self._ctx)))
         self.n_rows = self.n_edges = self.n_table = 0

@@ -155,6 +155,9 @@ struct Scope {      // brackets the launches of one kernel class with a HIP even
     }
 };
 
+static bool bf16(const gat_ctx* c) { return c->cfg.storage_dtype == GAT_DTYPE_BF16; }
+static int64_t st_bytes(const gat_ctx* c) { return bf16(c) ? 2 : 4; }       // element size of PL / message rows
+
 static int check_layer(gat_ctx* c, int32_t l) {
     if (!c) return fail(GAT_E_INVALID, "null context");
     if (l < 0 || l >= c->cfg.num_layers) return fail(GAT_E_INVALID, "layer index out of range");
@@ -178,7 +181,9 @@ static int ensure_buffers(gat_ctx* c) {
     const int64_t N = c->n_rows, E = c->n_edges, T = c->n_table;
     for (int l = 0; l < L; ++l) {
         Layer& y = c->layers[l];
-        if (!y.PL_bound) GAT_TRY(dalloc(c, &y.PL, T * y.HD));
+        if (bf16(c) && !edge_fast_path(y.H, y.D, T))
+            return fail(GAT_E_UNSUPPORTED, "bf16 storage needs every layer on the wave-per-row path (H*D in {8,16,32,64}, D a power of two)");
+        if (!y.PL_bound) GAT_TRY(dmalloc(c, (void**)&y.PL, (size_t)(T * y.HD * st_bytes(c))));
         GAT_TRY(dalloc(c, &y.PR, N * y.HD));
         // attn_coeff [E][H] is only materialised for parity taps and for layers on the generic
         // path; the fast path's backward recomputes it from the per-(row, head) softmax stats.
@@ -212,7 +217,7 @@ static int ensure_buffers(gat_ctx* c) {
     const char* force = getenv("GAT_BWD_ATOMICS");
     if (msg_hd > 0 && E > 0 && !(force && force[0] == '1')) {
         float* m = nullptr;
-        if (hipMalloc((void**)&m, (size_t)E * msg_hd * sizeof(float)) == hipSuccess) {
+        if (hipMalloc((void**)&m, (size_t)E * msg_hd * (size_t)st_bytes(c)) == hipSuccess) {
             c->owned.push_back(m);
             c->msg = m; c->msg_hd = msg_hd;
             GAT_TRY(dalloc(c, &c->csc_pos, E));
@@ -297,6 +302,8 @@ int gat_create(const gat_config* cfg, gat_ctx** out) {
     }
     c->nW = woff; c->nA = aoff;
     c->nWo = (int64_t)cfg->num_classes * c->layers.back().D;
+    if (cfg->storage_dtype != GAT_DTYPE_F32 && cfg->storage_dtype != GAT_DTYPE_BF16)
+        return fail(GAT_E_INVALID, "storage_dtype must be GAT_DTYPE_F32 or GAT_DTYPE_BF16");
     if (const char* d = getenv("GAT_DBG")) c->dbg = atoi(d);
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { GAT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -528,11 +535,11 @@ int gat_layer_project(gat_ctx* c, int32_t l) {
     Layer& y = c->layers[l];
     Scope t(c, GAT_K_PROJECT);
     if (l == 0 && c->Xtab) {      // replicated input: whole PL table from the table rows, PR from the shard's rows
-        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, c->stream));
-        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, c->stream);
+        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->stream));
+        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->stream);
     }
-    return launch_project(Xin_of(c, l), W_of(c, l), y.PL + c->table_row0 * y.HD, y.PR, c->n_rows, y.F, y.HD, kPartBoth,
-                          c->stream);
+    float* own_rows = reinterpret_cast<float*>(reinterpret_cast<char*>(y.PL) + c->table_row0 * y.HD * st_bytes(c));
+    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->stream);
 }
 
 int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
@@ -541,7 +548,7 @@ int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
     EdgeFwdArgs a{};
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
     a.alpha = y.alpha; a.hpre = y.hpre; a.hout = y.hout; a.mstat = y.mstat; a.zstat = y.zstat;
-    a.n_rows = c->n_rows; a.n_table = c->n_table; a.H = y.H; a.D = y.D; a.is_last = (l == c->cfg.num_layers - 1);
+    a.n_rows = c->n_rows; a.n_table = c->n_table; a.bf16 = bf16(c); a.H = y.H; a.D = y.D; a.is_last = (l == c->cfg.num_layers - 1);
     a.slope = c->cfg.negative_slope;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
     a.part_acc = c->part_acc; a.part_mz = c->part_mz;
@@ -599,9 +606,9 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
     a.part_acc = c->part_acc;
     a.dbg = c->dbg;
-    a.ga_partial = c->ga_partial; a.n_rows = c->n_rows; a.n_table = c->n_table; a.H = y.H; a.D = y.D;
-    a.ga_blocks = edge_fast_path(y.H, y.D, c->n_table) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr)
-                                           : edge_backward_blocks(c->n_rows * 4, y.H, y.D, false, false);
+    a.ga_partial = c->ga_partial; a.n_rows = c->n_rows; a.n_table = c->n_table; a.bf16 = bf16(c); a.H = y.H; a.D = y.D;
+    a.ga_blocks = edge_fast_path(y.H, y.D, c->n_table) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr, bf16(c))
+                                           : edge_backward_blocks(c->n_rows * 4, y.H, y.D, false, false, false);
     a.slope = c->cfg.negative_slope;
     {
         Scope t(c, GAT_K_EDGE_BWD);
@@ -609,7 +616,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     }
     if (store) {
         Scope t(c, GAT_K_GPL_SUM);
-        GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, c->stream));
+        GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, bf16(c), c->stream));
     }
     Scope t(c, GAT_K_MISC);
     return launch_reduce_partials_add(c->ga_partial, a.ga_blocks, y.HD, ga_of(c, l), c->stream);
@@ -635,7 +642,8 @@ int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
 }
 
 // ---- whole step (single shard, or a shard with a transport attached) ------------------------------------------
-static int64_t table_slice(gat_ctx* c, const Layer& y) { return (c->n_table / c->comm->world) * y.HD; }
+static int64_t table_slice(gat_ctx* c, const Layer& y) { return (c->n_table / c->comm->world) * y.HD; }      // fp32 rows
+static int64_t pl_slice(gat_ctx* c, const Layer& y) { return table_slice(c, y) * st_bytes(c) / 4; }        // PL rows, as floats
 static bool needs_exchange(gat_ctx* c, int l) { return c->n_table != c->n_rows && !(l == 0 && c->Xtab); }
 static int check_step(gat_ctx* c, const char* who) {
     GAT_TRY(check_layer(c, 0));
@@ -649,7 +657,7 @@ static int forward_phases(gat_ctx* c) {
         GAT_TRY(gat_layer_project(c, l));
         if (c->comm && needs_exchange(c, l)) {
             Scope t(c, GAT_K_EXCHANGE);
-            GAT_TRY(c->comm->all_gather(c->layers[l].PL, table_slice(c, c->layers[l]), c->stream));
+            GAT_TRY(c->comm->all_gather(c->layers[l].PL, pl_slice(c, c->layers[l]), c->stream));
         }
         GAT_TRY(gat_layer_forward_edges(c, l));
     }
@@ -780,7 +788,7 @@ int gat_table(gat_ctx* c, int which, int32_t l, void** d_ptr, int64_t* n_rows, i
     else if (which == GAT_TABLE_GPL) *d_ptr = c->gPL;
     else return fail(GAT_E_INVALID, "unknown table");
     if (n_rows) *n_rows = c->n_table;
-    if (row_floats) *row_floats = c->layers[l].HD;
+    if (row_floats) *row_floats = which == GAT_TABLE_PL ? c->layers[l].HD * st_bytes(c) / 4 : c->layers[l].HD;
     return 0;
 }
 int gat_bind_table(gat_ctx* c, int which, int32_t l, void* d_ptr, int64_t bytes) {
@@ -789,7 +797,7 @@ int gat_bind_table(gat_ctx* c, int which, int32_t l, void* d_ptr, int64_t bytes)
     if (!c->have_graph) return fail(GAT_E_STATE, "gat_bind_table: set the graph first");
     if (which == GAT_TABLE_PL) {
         Layer& y = c->layers[l];
-        if (bytes < (int64_t)c->n_table * y.HD * (int64_t)sizeof(float)) return fail(GAT_E_INVALID, "bound PL table too small");
+        if (bytes < (int64_t)c->n_table * y.HD * st_bytes(c)) return fail(GAT_E_INVALID, "bound PL table too small");
         if (!y.PL_bound) dfree(c, y.PL);
         y.PL = (float*)d_ptr; y.PL_bound = true;
         return 0;
@@ -853,7 +861,17 @@ int gat_tap(gat_ctx* c, int tensor, int32_t l, void* host, int64_t count) {
         case GAT_TAP_HOUT: { const int64_t n = N * (last ? y.D : y.HD); GAT_TRY(need(n)); return d2h(c, host, y.hout, n * sizeof(float)); }
         case GAT_TAP_Y: GAT_TRY(need(N * c->cfg.num_classes)); return d2h(c, host, c->y, N * c->cfg.num_classes * sizeof(float));
         case GAT_TAP_G: GAT_TRY(need(N * y.HD)); return d2h(c, host, y.g, N * y.HD * sizeof(float));
-        case GAT_TAP_PL: GAT_TRY(need(c->n_table * y.HD)); return d2h(c, host, y.PL, c->n_table * y.HD * sizeof(float));
+        case GAT_TAP_PL: {
+            GAT_TRY(need(c->n_table * y.HD));
+            if (!bf16(c)) return d2h(c, host, y.PL, c->n_table * y.HD * sizeof(float));
+            std::vector<uint16_t> hb((size_t)(c->n_table * y.HD));          // bf16 rows -> fp32 for the caller
+            GAT_TRY(d2h(c, hb.data(), y.PL, hb.size() * sizeof(uint16_t)));
+            for (size_t i = 0; i < hb.size(); ++i) {
+                const uint32_t u = (uint32_t)hb[i] << 16;
+                memcpy(static_cast<float*>(host) + i, &u, sizeof(float));
+            }
+            return 0;
+        }
         case GAT_TAP_PR: GAT_TRY(need(N * y.HD)); return d2h(c, host, y.PR, N * y.HD * sizeof(float));
         default: return fail(GAT_E_INVALID, "gat_tap: unknown tensor id");
     }
@@ -907,7 +925,7 @@ int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, con
     float *PL, *PR, *alpha, *ms, *zs;
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
     GAT_TRY(t.get(&ms, n * h)); GAT_TRY(t.get(&zs, n * h));
-    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, s));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, s));
     EdgeFwdArgs a{};
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
     a.mstat = ms; a.zstat = zs;
@@ -935,7 +953,7 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
     GAT_TRY(t.get(&gPL, n * HD)); GAT_TRY(t.get(&gPR, n * HD)); GAT_TRY(t.get(&gap, (int64_t)blocks * HD));
     GAT_TRY(t.get(&scr, grad_w_scratch_floats(n, f, HD)));
-    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, s));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, s));
     GAT_TRY(launch_transpose_he_to_eh(d_attn_coeff, alpha, e, h, s));
     GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
     // softmax stats of this layer (the fast-path backward recomputes alpha from them): one
@@ -956,8 +974,8 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     a.mstat = ms; a.zstat = zs;
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
     a.hpre = d_hpre; a.g = d_g; a.gPL = gPL; a.gPR = gPR; a.ge = nullptr; a.ga_partial = gap;
-    a.ga_blocks = edge_fast_path(h, d, n) ? edge_backward_blocks(t.w.n_items, h, d, false, false)
-                                       : edge_backward_blocks(n * 4, h, d, false, false);
+    a.ga_blocks = edge_fast_path(h, d, n) ? edge_backward_blocks(t.w.n_items, h, d, false, false, false)
+                                       : edge_backward_blocks(n * 4, h, d, false, false, false);
     a.n_rows = n; a.n_table = n; a.H = h; a.D = d; a.slope = slope;
     a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots;
     a.part_acc = t.part_acc;

@@ -73,6 +73,52 @@ __global__ __launch_bounds__(256) void gpl_sum_kernel(const int32_t* __restrict_
     if (r == 0) reinterpret_cast<float4*>(gPL)[s * LPR + q] = acc;
 }
 
+// bf16 message rows (cfg.storage_dtype): a row is HD*2 bytes, one 16-byte load = 8 channels, HD/8 lanes per
+// row; accumulation and the gPL output stay fp32.  One source per group of HD/8 lanes walking its slots
+// (U loads in flight); sources with long lists are finished by the whole wave like in the group kernel.
+template <int HD>
+__global__ __launch_bounds__(256) void gpl_sum_bf16_kernel(const int32_t* __restrict__ src_ptr,
+                                                           const float* __restrict__ msg, float* __restrict__ gPL,
+                                                           int64_t n_table) {
+    constexpr int LPR = HD / 8, RPI = 64 / LPR, U = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane % LPR, r = lane / LPR;
+    const int64_t s = (int64_t)blockIdx.x * 4 + wave;
+    if (s >= n_table) return;
+    const int b = src_ptr[s], e = src_ptr[s + 1];
+    const uint4* m8 = reinterpret_cast<const uint4*>(msg);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int i0 = b; i0 < e; i0 += RPI * U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * RPI + r;
+            v[u] = (i < e) ? m8[(int64_t)i * LPR + q] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[2 * k] += __builtin_bit_cast(float, w[k] << 16);
+                acc[2 * k + 1] += __builtin_bit_cast(float, w[k] & 0xFFFF0000u);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], off);
+    if (r == 0) {
+        float4* out = reinterpret_cast<float4*>(gPL + s * HD + q * 8);
+        out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
 // Same sum for short lists (a shard sees ~deg/P slots per source): one source per GROUP of HD/4
 // lanes, 64/(HD/4) sources per wave, each group walking its own slots — no cross-lane reduction and
 // 64/(HD/4) times fewer waves.  Sources with more than kGroupMax slots are handed to the whole
@@ -166,8 +212,20 @@ int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t*
 }
 
 int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
-                   int32_t HD, hipStream_t s) {
+                   int32_t HD, bool msg_bf16, hipStream_t s) {
     if (n_table <= 0) return 0;
+    if (msg_bf16) {
+        const dim3 grid((unsigned)((n_table + 3) / 4)), block(256);
+        switch (HD) {
+            case 64: hipLaunchKernelGGL(gpl_sum_bf16_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+            case 32: hipLaunchKernelGGL(gpl_sum_bf16_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+            case 16: hipLaunchKernelGGL(gpl_sum_bf16_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+            case 8: hipLaunchKernelGGL(gpl_sum_bf16_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+            default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
+        }
+        GAT_HIP(hipGetLastError());
+        return 0;
+    }
     static const char* force = getenv("GAT_GPL_GROUP");          // A/B switch: 0 = wave per source, 1 = group per source
     const bool group = force ? force[0] == '1' : n_slots < 8 * n_table;   // measured: 3.2 slots/source 1.24 -> 1.00 ms, 12.6: 3.20 -> 3.31
     if (group && HD >= 8 && HD <= 64) {

@@ -173,29 +173,48 @@ __device__ __forceinline__ int per_lane(int x) {
 // PL[row][c] with the address as uniform base + 32-bit byte offset: one v_lshl_add_u32 per gather and
 // the `global_load_dword v, voff, s[base]` form, instead of a sign-extension and two 64-bit VALU ops.
 // Valid while the table is < 4 GiB (n_table * H*D * 4; checked by the launchers).
-template <int HD>
+// BF: the table / message rows are stored as bf16 (cfg.storage_dtype; halves the gathered, stored and
+// exchanged bytes — arithmetic stays fp32).  bf16 -> f32 is a 16-bit shift; f32 -> bf16 rounds to
+// nearest even.
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+template <int HD, bool BF>
 __device__ __forceinline__ float gather_row(const float* __restrict__ table, int row, int c) {
-    const uint32_t off = (uint32_t)row * (uint32_t)(HD * 4) + (uint32_t)c * 4u;
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + off);
+    if constexpr (BF) {
+        const uint32_t off = (uint32_t)row * (uint32_t)(HD * 2) + (uint32_t)c * 2u;
+        return bf16_to_f32(*reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(table) + off));
+    } else {
+        const uint32_t off = (uint32_t)row * (uint32_t)(HD * 4) + (uint32_t)c * 4u;
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + off);
+    }
 }
 // msg[slot][c] = v.  The message array is E*H*D*4 bytes (15.8 GB on the benchmark graph): 64-bit row
 // base.  When the whole wave works on one edge the slot is wave-uniform: row base on the SALU,
 // lane offset in a VGPR (`global_store_dword voff, v, s[base]`), no VALU address math.
-template <int HD, bool UNIFORM>
+template <int HD, bool UNIFORM, bool BF>
 __device__ __forceinline__ void store_row(float* __restrict__ msg, int slot, int c, float v) {
+    constexpr int ES = BF ? 2 : 4;
+    char* rowb;
+    uint32_t off;
     if constexpr (UNIFORM) {
-        char* rowb = reinterpret_cast<char*>(msg) + ((int64_t)__builtin_amdgcn_readfirstlane(slot) * (HD * 4));
+        rowb = reinterpret_cast<char*>(msg) + ((int64_t)__builtin_amdgcn_readfirstlane(slot) * (HD * ES));
         // the lane offset must reach instruction selection as an opaque zext(i32) next to the scalar base: a
         // visible c*4 is re-associated into (msg + c*4) + slot*row, i.e. a 64-bit VALU add per store
-        *reinterpret_cast<float*>(rowb + (uint32_t)per_lane(c * 4)) = v;
+        off = (uint32_t)per_lane(c * ES);
     } else {
-        (msg + (int64_t)slot * HD)[(unsigned)c] = v;
+        rowb = reinterpret_cast<char*>(msg) + (int64_t)slot * (HD * ES);
+        off = (uint32_t)(c * ES);
     }
+    if constexpr (BF) *reinterpret_cast<uint16_t*>(rowb + off) = f32_to_bf16(v);
+    else *reinterpret_cast<float*>(rowb + off) = v;
 }
 
 // One chunk of UU slots per edge group: UU independent gathers issued back to back (indices
 // clamped into the item, so loads need no predicate), then scores, then the online-softmax update.
-template <int HD, int D, int UU, int USC, bool ALPHA>
+template <int HD, int D, int UU, int USC, bool ALPHA, bool BF>
 __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_end, int e_end_v, int c, int gidx,
                                           float pr, float ac2, bool multi, float (&sc)[USC], float& m, float& Z,
                                           float& acc) {
@@ -206,7 +225,7 @@ __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_en
     for (int u = 0; u < UU; ++u) {
         const int j = e0 + u * G + gidx;
         const int jc = j < e_end ? j : e_end - 1;
-        v[u] = gather_row<HD>(A.PL, A.col_idx[jc], c);
+        v[u] = gather_row<HD, BF>(A.PL, A.col_idx[jc], c);
     }
     // scores: the cross-lane stages run slot-interleaved (UU independent DPP chains), so that no
     // stage waits on the VALU->DPP hazard of its own predecessor
@@ -243,7 +262,7 @@ __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_en
 }
 
 // ALPHA: also materialise attn_coeff [E][H] (parity taps only; the training path never needs it).
-template <int HD, int D, bool ALPHA>
+template <int HD, int D, bool ALPHA, bool BF = false>
 __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
     constexpr int G = 64 / HD;      // edges per wave-instruction
     constexpr int U = 16 / G;       // gathers in flight per group
@@ -269,10 +288,10 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdArgs A) {
 
     for (int e0 = b; e0 < e_end; e0 += CH) {
         if constexpr (U >= 2) {
-            if (e_end - e0 <= CH / 2) fwd_chunk<HD, D, U / 2, U, ALPHA>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
-            else fwd_chunk<HD, D, U, U, ALPHA>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
+            if (e_end - e0 <= CH / 2) fwd_chunk<HD, D, U / 2, U, ALPHA, BF>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
+            else fwd_chunk<HD, D, U, U, ALPHA, BF>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
         } else {
-            fwd_chunk<HD, D, U, U, ALPHA>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
+            fwd_chunk<HD, D, U, U, ALPHA, BF>(A, e0, e_end, e_end_v, c, gidx, pr, ac2, multi, sc, m, Z, acc);
         }
     }
 
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(256) void edge_fwd_fix_kernel(EdgeFwdArgs A) {
 //   grad_a += ge LReLU(s)   gPR[dst] += gs   gPL[src] += g alpha + gs   (E:769-782, 859-869)
 // STORE: message row -> its CSC slot (summed per source by gpl_sum_kernel); else float atomics.
 // ------------------------------------------------------------------------------------------------
-template <int HD, int D, int UU, bool STORE, bool TAPS, int DBG>
+template <int HD, int D, int UU, bool STORE, bool TAPS, int DBG, bool BF>
 __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_end, int e_end_v, int c, int gidx,
                                           float g, float pr, float dot, float ac, float ac2, float m2, float inv,
                                           float& ga, float& gpr) {
@@ -366,7 +385,7 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
         const int j = e0 + u * G + gidx;
         const int jc = j < e_end ? j : e_end - 1;                // clamped: loads need no predicate
         const int src = A.col_idx[jc];
-        v[u] = gather_row<HD>(A.PL, src, c);
+        v[u] = gather_row<HD, BF>(A.PL, src, c);
         if constexpr (STORE) sid[u] = (DBG == 2) ? jc : A.pos[jc]; else sid[u] = src;
     }
     // Compute in passes of P <= 8 slots (bounds the live registers; the first pass starts as soon as
@@ -396,7 +415,7 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
             gpr += gs;
             const float msg = fmaf(g, al[q], gs);                // d/dPL[src] from this edge
             if (valid && DBG != 1) {
-                if constexpr (STORE) store_row<HD, G == 1>(A.msg, sid[u], c, msg);
+                if constexpr (STORE) store_row<HD, G == 1, BF>(A.msg, sid[u], c, msg);
                 else unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, msg);
             }
             if constexpr (TAPS) {
@@ -406,7 +425,7 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
     }
 }
 
-template <int HD, int D, bool STORE, bool TAPS, int DBG = 0>
+template <int HD, int D, bool STORE, bool TAPS, int DBG = 0, bool BF = false>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
     constexpr int G = 64 / HD;
     constexpr int U = 16 / G;
@@ -433,10 +452,10 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
         float gpr = 0.f;
         for (int e0 = b; e0 < e_end; e0 += CH) {
             if constexpr (U >= 2) {
-                if (e_end - e0 <= CH / 2) bwd_chunk<HD, D, U / 2, STORE, TAPS, DBG>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ac2, m2, inv, ga, gpr);
-                else bwd_chunk<HD, D, U, STORE, TAPS, DBG>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ac2, m2, inv, ga, gpr);
+                if (e_end - e0 <= CH / 2) bwd_chunk<HD, D, U / 2, STORE, TAPS, DBG, BF>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ac2, m2, inv, ga, gpr);
+                else bwd_chunk<HD, D, U, STORE, TAPS, DBG, BF>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ac2, m2, inv, ga, gpr);
             } else {
-                bwd_chunk<HD, D, U, STORE, TAPS, DBG>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ac2, m2, inv, ga, gpr);
+                bwd_chunk<HD, D, U, STORE, TAPS, DBG, BF>(A, e0, e_end, e_end_v, c, gidx, g, pr, dot, ac, ac2, m2, inv, ga, gpr);
             }
         }
 #pragma unroll
@@ -595,10 +614,12 @@ int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
     if (a.mstat == nullptr || a.zstat == nullptr) return fail(GAT_E_INVALID, "edge_forward: stats buffers missing");
     const dim3 grid((unsigned)blocks), fgrid((unsigned)((a.n_slots + 3) / 4)), block(256);
     if (a.alpha != nullptr) {
-        hipLaunchKernelGGL((edge_fwd_kernel<HD, D, true>), grid, block, 0, s, a);
+        if (a.bf16) hipLaunchKernelGGL((edge_fwd_kernel<HD, D, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((edge_fwd_kernel<HD, D, true, false>), grid, block, 0, s, a);
         if (a.n_slots > 0) hipLaunchKernelGGL((edge_fwd_fix_kernel<HD, D, true>), fgrid, block, 0, s, a);
     } else {
-        hipLaunchKernelGGL((edge_fwd_kernel<HD, D, false>), grid, block, 0, s, a);
+        if (a.bf16) hipLaunchKernelGGL((edge_fwd_kernel<HD, D, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((edge_fwd_kernel<HD, D, false, false>), grid, block, 0, s, a);
         if (a.n_slots > 0) hipLaunchKernelGGL((edge_fwd_fix_kernel<HD, D, false>), fgrid, block, 0, s, a);
     }
     GAT_HIP(hipGetLastError());
@@ -621,12 +642,15 @@ static int resident_blocks(const void* fn) {
     (void)hipGetLastError();
     return cache[fn] = per_cu * (cus > 0 ? cus : 256);
 }
-struct BwdSel { bool store, taps; };
+struct BwdSel { bool store, taps, bf16; };
+template <int HD, int D, bool BF>
+const void* bwd_variant(bool store, bool taps) {
+    return store ? (taps ? (const void*)edge_bwd_kernel<HD, D, true, true, 0, BF> : (const void*)edge_bwd_kernel<HD, D, true, false, 0, BF>)
+                 : (taps ? (const void*)edge_bwd_kernel<HD, D, false, true, 0, BF> : (const void*)edge_bwd_kernel<HD, D, false, false, 0, BF>);
+}
 template <int HD, int D>
 int bwd_resident(const BwdSel& sel, hipStream_t) {
-    const void* fn = sel.store ? (sel.taps ? (const void*)edge_bwd_kernel<HD, D, true, true> : (const void*)edge_bwd_kernel<HD, D, true, false>)
-                               : (sel.taps ? (const void*)edge_bwd_kernel<HD, D, false, true> : (const void*)edge_bwd_kernel<HD, D, false, false>);
-    return resident_blocks(fn);
+    return resident_blocks(sel.bf16 ? bwd_variant<HD, D, true>(sel.store, sel.taps) : bwd_variant<HD, D, false>(sel.store, sel.taps));
 }
 
 template <int HD, int D>
@@ -638,10 +662,17 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
         if (store && !taps && a.dbg == 1) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 1>), grid, block, 0, s, a); return 0; }
         if (store && !taps && a.dbg == 2) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 2>), grid, block, 0, s, a); return 0; }
     }
-    if (store && taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, true>), grid, block, 0, s, a);
-    else if (store) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false>), grid, block, 0, s, a);
-    else if (taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, false>), grid, block, 0, s, a);
+    if (a.bf16) {
+        if (store && taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, true, 0, true>), grid, block, 0, s, a);
+        else if (store) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 0, true>), grid, block, 0, s, a);
+        else if (taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, true, 0, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, false, 0, true>), grid, block, 0, s, a);
+    } else {
+        if (store && taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, true>), grid, block, 0, s, a);
+        else if (store) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false>), grid, block, 0, s, a);
+        else if (taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, false>), grid, block, 0, s, a);
+    }
     GAT_HIP(hipGetLastError());
     if (a.n_slots > 0) {
         const int64_t threads = (int64_t)a.n_slots * HD;
@@ -685,11 +716,11 @@ int launch_edge_forward(const EdgeFwdArgs& a, hipStream_t s) {
     return 0;
 }
 
-int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D_, bool store, bool taps) {
+int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D_, bool store, bool taps, bool bf16) {
     int64_t want = (n_items + 3) / 4;
     if (want < 1) want = 1;
     const int HD = H * D_, D = D_;
-    const BwdSel sel{store, taps};
+    const BwdSel sel{store, taps, bf16};
     auto cap = [&]() -> int {
         GAT_DISPATCH_HD_D(bwd_resident, sel, nullptr)
         return 2048;                                  // generic path: one wave per block

@@ -62,14 +62,24 @@ struct BSrcGradX {                // B(k=c, j=f): c < HD ? W[c][f] : W[c-HD][F+f
     static constexpr bool kAlongK = false;
 };
 // ---- epilogues ---------------------------------------------------------------------------------------
-struct EpiProject {               // cols j0+j < HD -> PL rows, else PR
+template <bool BF>
+struct EpiProject {               // cols j0+j < HD -> PL rows (bf16 rows when BF: round to nearest even), else PR
     static constexpr bool kTwoPhase = false;
     float* PL; float* PR; int32_t HD, j0;
     __device__ __forceinline__ float pre(int64_t, int) const { return 0.f; }
     __device__ __forceinline__ void apply(int64_t i, int j, float v, float) const { (*this)(i, j, v); }
     __device__ __forceinline__ void operator()(int64_t i, int j, float v) const {
         j += j0;
-        if (j < HD) PL[i * HD + j] = v; else PR[i * HD + (j - HD)] = v;
+        if (j < HD) {
+            if constexpr (BF) {
+                const uint32_t u = __builtin_bit_cast(uint32_t, v);
+                reinterpret_cast<uint16_t*>(PL)[i * HD + j] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+            } else {
+                PL[i * HD + j] = v;
+            }
+        } else {
+            PR[i * HD + (j - HD)] = v;
+        }
     }
 };
 struct EpiGradX {                 // g_prev = gX ⊙ LReLU'(h_pre_prev)   (E:888-892)
@@ -352,13 +362,14 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace
 
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows, int32_t F,
-                   int32_t HD, int32_t part, hipStream_t s) {
+                   int32_t HD, int32_t part, bool pl_bf16, hipStream_t s) {
     const int32_t j0 = part == kPartRight ? HD : 0;
     ASrcRows as{X, F};
     BSrcProject bs{W, F, HD, j0};
-    EpiProject ep{PL_rows, PR, HD, j0};
     const bool vec4 = (F % 4 == 0) && aligned16(X);
-    return run_rowgemm(as, bs, ep, n_rows, part == kPartBoth ? 2 * HD : HD, F, vec4, s);
+    const int32_t N = part == kPartBoth ? 2 * HD : HD;
+    if (pl_bf16) return run_rowgemm(as, bs, EpiProject<true>{PL_rows, PR, HD, j0}, n_rows, N, F, vec4, s);
+    return run_rowgemm(as, bs, EpiProject<false>{PL_rows, PR, HD, j0}, n_rows, N, F, vec4, s);
 }
 
 int launch_grad_x(const float* gPL_rows, const float* gPR, const float* W, const float* hpre_prev,

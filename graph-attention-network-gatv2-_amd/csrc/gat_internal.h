@@ -43,6 +43,7 @@ struct EdgeFwdArgs {
     float* zstat;             // [n_rows][H] softmax sum
     int64_t n_rows;
     int64_t n_table;          // rows of the gathered PL table (fast path: < 4 GiB, see edge_fast_path)
+    int32_t bf16;             // PL (and msg) rows stored as bf16 (cfg.storage_dtype)
     int32_t H, D;
     int32_t is_last;
     float slope;
@@ -88,6 +89,7 @@ struct EdgeBwdArgs {
     int32_t ga_blocks;        // grid size the launcher must use (== rows of ga_partial)
     int64_t n_rows;
     int64_t n_table;          // rows of the gathered PL table (fast path: < 4 GiB, see edge_fast_path)
+    int32_t bf16;             // PL (and msg) rows stored as bf16 (cfg.storage_dtype)
     int32_t H, D;
     float slope;
     const int4* items;        // as in EdgeFwdArgs
@@ -99,7 +101,7 @@ struct EdgeBwdArgs {
 };
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s);
 // Grid size (== rows of ga_partial) for the backward of an (H, D) layer over n_items work items.
-int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D, bool store, bool taps);
+int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D, bool store, bool taps, bool bf16);
 // wave-per-row templates cover this (H, D), and the gathered table is < 4 GiB (they address it as
 // uniform base + 32-bit byte offset); anything else runs the generic kernels
 bool edge_fast_path(int32_t H, int32_t D, int64_t n_table);
@@ -108,7 +110,7 @@ bool edge_fast_path(int32_t H, int32_t D, int64_t n_table);
 int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t* pos, int32_t* src_ptr,
               hipStream_t s);
 int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
-                   int32_t HD, hipStream_t s);
+                   int32_t HD, bool msg_bf16, hipStream_t s);
 
 int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);
@@ -151,8 +153,9 @@ int launch_transpose_nh_to_hn(const float* src_nh, float* dst_hn, int64_t N, int
 // part: both halves in one pass over X, or only the W_left (PL) / W_right (PR) half — the two halves run over
 // different row sets when the layer input is replicated on every shard (gat_set_source_features).
 enum : int32_t { kPartBoth = 0, kPartLeft = 1, kPartRight = 2 };
+// pl_bf16: PL_rows points at bf16 rows ([.][HD] of 2 bytes) — cfg.storage_dtype
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows,
-                   int32_t F, int32_t HD, int32_t part, hipStream_t s);
+                   int32_t F, int32_t HD, int32_t part, bool pl_bf16, hipStream_t s);
 // gradW[j][0:F] += sum_n gPL[n][j] X[n][:],  gradW[j][F:2F] += sum_n gPR[n][j] X[n][:]
 // scratch: at least grad_w_scratch_floats(n_rows, F, HD) floats.
 int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);

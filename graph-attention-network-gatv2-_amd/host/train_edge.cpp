@@ -14,6 +14,8 @@
 // "host" stages them through shared memory and lets ranks share a GPU — for testing).  Every rank
 // reads the dataset, keeps its destination range (host/shard_plan.h) and the replicated input
 // features; rank 0 prints.  Same numbers as one GPU up to fp32 summation order.
+// --dtype f32|bf16: storage type of the gathered / exchanged source table and the per-edge message
+// rows (arithmetic stays fp32).
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -56,6 +58,7 @@ struct Options {
     bool cache = false;
     int ranks = 1;
     std::string transport = "rccl";
+    std::string dtype = "f32";
 };
 
 struct RankEnv {                      // one forked process per GPU
@@ -119,6 +122,9 @@ Options parse_args(int argc, char** argv) {
         else if (a == "--ranks" && has_val) {
             o.ranks = std::stoi(argv[++i]);
             if (o.ranks < 1) die("Error: --ranks must be >= 1\n");
+        } else if (a == "--dtype" && has_val) {
+            o.dtype = argv[++i];
+            if (o.dtype != "f32" && o.dtype != "bf16") die("Invalid dtype choice. Use 'f32' or 'bf16'\n");
         } else if (a == "--transport" && has_val) {
             o.transport = argv[++i];
             if (o.transport != "rccl" && o.transport != "host") die("Invalid transport choice. Use 'rccl' or 'host'\n");
@@ -313,6 +319,7 @@ int run(const Options& o, const RankEnv& env) {
     gat_config cfg{};
     cfg.num_layers = L; cfg.heads = o.heads.data(); cfg.outdims = o.outdims.data();
     cfg.in_dim = F0; cfg.num_classes = C; cfg.negative_slope = 0.01f; cfg.device = o.device;
+    cfg.storage_dtype = o.dtype == "bf16" ? GAT_DTYPE_BF16 : GAT_DTYPE_F32;
     int n_devices = 0;
     check(gat_device_count(&n_devices), "gat_device_count");
     if (env.world > 1) {

@@ -171,8 +171,9 @@ class ShardedGat:
         self.hd = [int(h) * int(d) for h, d in zip(heads, outdims)]
         self.L = len(self.hd)
         self.pl = []
+        sb = getattr(ctx, "storage_bytes", 4)          # bf16 storage: PL rows are H*D*2 bytes
         for l in range(self.L):
-            t = alloc(plan.n_table * self.hd[l])
+            t = alloc(plan.n_table * self.hd[l] * sb // 4)
             ctx.bind_table(0, l, t.data_ptr(), t.numel() * 4)
             self.pl.append(t)
         self.gpl = alloc(plan.n_table * max(self.hd))

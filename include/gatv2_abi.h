@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAT_ABI_VERSION 1
+#define GAT_ABI_VERSION 2
 
 enum {
     GAT_OK = 0,
@@ -55,7 +55,12 @@ typedef struct gat_config {
                                   1 = the reference's flat index n*D+d (E:598) */
     int32_t collect_timing;    /* 1 = bracket every kernel with hipEvents (gat_kernel_stats) */
     int32_t keep_taps;         /* 1 = also keep tensors only parity tests read (ge, max, sum) */
+    int32_t storage_dtype;     /* GAT_DTYPE_F32 (default) | GAT_DTYPE_BF16: the projected source table PL (gathered
+                                  per edge, exchanged between shards) and the per-edge message rows are STORED as
+                                  bf16; every sum, the softmax and all other tensors stay fp32.  BASELINE config 5
+                                  ("bf16"); parity bar vs the fp32 oracle: alpha, loss 1e-2. */
 } gat_config;
+enum { GAT_DTYPE_F32 = 0, GAT_DTYPE_BF16 = 1 };
 
 const char* gat_last_error(void);
 int gat_abi_version(void);
