@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--exchange-layer0", action="store_true",
                     help="N>1: do not replicate the input features; all-gather / reduce-scatter layer 0 too (A/B)")
     ap.add_argument("--cpu-sample-scale", type=float, default=0.0, help="0 = auto (~15 s of CPU work)")
+    ap.add_argument("--graph", action="store_true",
+                    help="N=1: replay the step as one hipGraph launch (launch-bound small graphs: cora / pubmed / "
+                         "arxiv); per-kernel event timing, hence the roofline object, is not available in this mode")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="storage type of the gathered / exchanged PL table and the message rows (BASELINE config 5 "
@@ -139,8 +142,9 @@ def main():
     row_ptr, col_idx = pkg.synth.powerlaw_graph(n, e, beta=args.beta)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        ctx = pkg.GatContext(heads, outdims, f, c, device=local_rank, stream=stream.cuda_stream, collect_timing=True,
-                             dtype=args.dtype)
+        use_graph = args.graph and world == 1 and os.environ.get("GAT_FORCE_SHARDED") != "1"
+        ctx = pkg.GatContext(heads, outdims, f, c, device=local_rank, stream=stream.cuda_stream,
+                             collect_timing=not use_graph, dtype=args.dtype)
         force_sharded = os.environ.get("GAT_FORCE_SHARDED") == "1"     # rehearse the N>1 code path on one GPU
         if world == 1 and force_sharded:
             import torch.distributed as dist
@@ -185,8 +189,13 @@ def main():
         ctx.zero_grad()
         t_gen = time.perf_counter() - t_gen
 
+        if use_graph:
+            ctx.step_graph(True)
+
         def step():
-            if runner is None:
+            if use_graph:
+                out = ctx.step()
+            elif runner is None:
                 out = ctx.forward()
                 ctx.backward()
             else:
@@ -226,11 +235,13 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        dom = max((k for k in stats if stats[k][0] > 0 and k not in ("misc", "exchange")), key=lambda k: stats[k][1])
-        launches, tot_ms = stats[dom]
-        per_launch_bytes = bytes_k[dom] * args.steps / launches
-        avg_ms = tot_ms / launches
-        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        timed = [k for k in stats if stats[k][0] > 0 and k not in ("misc", "exchange")]
+        if timed:
+            dom = max(timed, key=lambda k: stats[k][1])
+            launches, tot_ms = stats[dom]
+            per_launch_bytes = bytes_k[dom] * args.steps / launches
+            avg_ms = tot_ms / launches
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         line = {
             "metric": "edges/sec (fwd+bwd, 2-layer 8-head GATv2)" if len(heads) == 2 else
                       f"edges/sec (fwd+bwd, {len(heads)}-layer 8-head GATv2)",
@@ -241,6 +252,7 @@ def main():
             "config": {
                 "workload": f"{args.workload}-shape synthetic power-law graph, {n} nodes / {e} edges / {f} feat / "
                             f"{c} classes, {len(heads)}-layer GATv2 heads {heads} outdims {outdims}, fp32",
+                "launch": "hipGraph replay" if use_graph else "eager",
                 "parallelism": (f"dst-range x{world}, " + ("all layers exchanged" if args.exchange_layer0 else
                                 "input features replicated (layer 0 exchange-free)") + f", exchanges: {comm_kind}")
                                if runner is not None else "single GPU",
@@ -251,7 +263,7 @@ def main():
                               "frac_of_8TBps_per_gpu": bytes_step_all / (dt / args.steps) / 1e9 / world / HBM_PEAK_GBS},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world, dom),
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch_bytes} if timed else None,
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in stats.items() if v[0] > 0},
         }
         if not args.no_cpu_baseline:

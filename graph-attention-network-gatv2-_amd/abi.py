@@ -127,6 +127,7 @@ def _declare(lib: C.CDLL) -> None:
         "gat_comm_init_rccl": [vp, i32, i32, vp],
         "gat_comm_init_host": [vp, i32, i32, C.c_char_p, i64],
         "gat_step": [vp, P(f32), P(i32)],
+        "gat_step_graph": [vp, i32],
         "gat_forward": [vp, P(f32), P(i32)],
         "gat_backward": [vp],
         "gat_zero_grad": [vp],
@@ -329,6 +330,10 @@ class GatContext:
         loss, corr = C.c_float(), C.c_int32()
         _chk(self.lib.gat_step(self._ctx, C.byref(loss), C.byref(corr)))
         return loss.value, corr.value
+
+    def step_graph(self, enable: bool = True):
+        """step() as one replayed hipGraph launch (small, launch-bound graphs)."""
+        _chk(self.lib.gat_step_graph(self._ctx, int(enable)))
 
     @staticmethod
     def comm_unique_id() -> bytes:

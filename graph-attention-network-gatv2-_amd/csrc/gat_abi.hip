@@ -77,6 +77,10 @@ struct gat_ctx {
     float* params = nullptr;   // [W | a | Wo]
     float* grads = nullptr;    // [gradW | grada | gradWo] + 4 floats of tail: [loss, correct lo, correct hi, -]
     std::unique_ptr<gat::Comm> comm;                // exchange transport of a shard (gat_comm_init_*)
+    // gat_step as a replayed hipGraph (gat_step_graph): 0 off, 1 armed (next step runs eagerly, then captures), 2 ready
+    int graph_state = 0, graph_warm = 0;
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    float* pinned_tail = nullptr;                   // [4] host-pinned landing zone of {loss, correct lo, correct hi}
     float* adam_m = nullptr; float* adam_v = nullptr;
     int32_t HDmax = 0, Hmax = 0;
     float* gPL = nullptr; bool gPL_bound = false;   // [n_table][HDmax]
@@ -324,6 +328,9 @@ int gat_destroy(gat_ctx* c) {
     for (auto& p : c->ev_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     c->comm.reset();
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    if (c->pinned_tail) (void)hipHostFree(c->pinned_tail);
     for (void* p : c->owned) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -707,8 +714,67 @@ int gat_backward(gat_ctx* c) {
     }
     return 0;
 }
+// The whole step as ONE graph launch: small graphs (Cora / Pubmed / Arxiv shapes) are launch-bound — ~25
+// kernels of a few microseconds each — so the sequence is captured once from the context's stream and
+// replayed.  First call after arming runs eagerly (fills the occupancy caches, which may not be queried
+// during capture), the second captures, later ones replay.  Everything the step touches has a fixed
+// address once the context is complete; gat_bind_table re-arms.
+static void graph_drop(gat_ctx* c) {
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    if (c->graph_state == 2) c->graph_state = 1;
+    c->graph_warm = 0;
+}
+static int step_body(gat_ctx* c) {
+    GAT_TRY(forward_phases(c));
+    GAT_TRY(gat_head_forward(c, nullptr, nullptr));
+    GAT_TRY(backward_phases(c));
+    return launch_pack_result(c->loss_out, c->correct_out, c->grads + c->nW + c->nA + c->nWo, c->stream);
+}
+static int step_graph(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
+    const int64_t np = c->nW + c->nA + c->nWo;
+    if (c->graph_state == 1 && c->graph_warm == 0) {            // eager warm-up
+        GAT_TRY(step_body(c));
+        c->graph_warm = 1;
+        return (loss_sum || n_correct) ? read_result_tail(c, loss_sum, n_correct) : 0;
+    }
+    if (c->graph_state == 1) {                                  // capture
+        if (!c->pinned_tail) GAT_HIP(hipHostMalloc((void**)&c->pinned_tail, 4 * sizeof(float)));
+        GAT_HIP(hipStreamSynchronize(c->stream));
+        GAT_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int rc = step_body(c);
+        if (rc == 0 && hipMemcpyAsync(c->pinned_tail, c->grads + np, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+            rc = fail(GAT_E_STATE, "gat_step_graph: capture of the result copy failed");
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc != 0 || e != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            c->graph_state = 0;                                     // fall back to eager for good
+            return rc != 0 ? rc : fail((int)e, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        }
+        c->graph = g;
+        GAT_HIP(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+        c->graph_state = 2;
+    }
+    GAT_HIP(hipGraphLaunch(c->graph_exec, c->stream));
+    if (!loss_sum && !n_correct) return 0;
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    if (loss_sum) *loss_sum = c->pinned_tail[0];
+    if (n_correct) *n_correct = (int32_t)(c->pinned_tail[1] + 4096.0f * c->pinned_tail[2] + 0.5f);
+    return 0;
+}
+int gat_step_graph(gat_ctx* c, int32_t enable) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    if (enable && c->comm) return fail(GAT_E_UNSUPPORTED, "gat_step_graph: not with a transport attached (the exchanges are issued eagerly)");
+    if (enable && c->cfg.collect_timing) return fail(GAT_E_UNSUPPORTED, "gat_step_graph: not with collect_timing (event pairs cannot be read back from a replay)");
+    graph_drop(c);
+    c->graph_state = enable ? 1 : 0;
+    return 0;
+}
 int gat_step(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
     GAT_TRY(check_step(c, "gat_step"));
+    if (c->graph_state != 0) return step_graph(c, loss_sum, n_correct);
     GAT_TRY(forward_phases(c));
     GAT_TRY(gat_head_forward(c, nullptr, nullptr));
     GAT_TRY(backward_phases(c));
@@ -795,6 +861,7 @@ int gat_bind_table(gat_ctx* c, int which, int32_t l, void* d_ptr, int64_t bytes)
     if (!c || !d_ptr) return fail(GAT_E_INVALID, "null argument");
     if (l < 0 || l >= c->cfg.num_layers) return fail(GAT_E_INVALID, "layer index out of range");
     if (!c->have_graph) return fail(GAT_E_STATE, "gat_bind_table: set the graph first");
+    graph_drop(c);                                       // captured addresses would be stale
     if (which == GAT_TABLE_PL) {
         Layer& y = c->layers[l];
         if (bytes < (int64_t)c->n_table * y.HD * st_bytes(c)) return fail(GAT_E_INVALID, "bound PL table too small");

@@ -3,6 +3,8 @@
 // optimizer and clip kernels.  (Projection GEMMs: gat_gemm_kernels.hip.)
 #include "gat_internal.h"
 
+#include <cstdlib>
+
 namespace gat {
 namespace {
 

@@ -156,6 +156,10 @@ int gat_comm_init_host(gat_ctx* ctx, int32_t world, int32_t rank, const char* sh
 /* forward + backward without a host round-trip in between; with a transport the loss and #correct
  * ride in the tail of the gradient all-reduce.  Returns the global loss sum / #correct. */
 int gat_step(gat_ctx* ctx, float* loss_sum, int32_t* n_correct);
+/* enable = 1: gat_step captures its kernel sequence into a hipGraph (after one eager step) and replays it —
+ * one launch per step instead of ~25; for graphs small enough to be launch-bound.  Single shard, no
+ * transport, collect_timing = 0.  Results are those of the eager step, bit for bit. */
+int gat_step_graph(gat_ctx* ctx, int32_t enable);
 
 /* Exchange buffers.  GAT_TABLE_PL: projected source features, [n_table][H_l*D_l] f32, the
  * context writes rows [table_row0, +n_rows) in gat_layer_project and reads all rows in the edge

@@ -267,3 +267,35 @@ def test_source_hub_both_gpl_sum_variants(pkg, orc, group, monkeypatch):
     env = dict(os.environ, GAT_GPL_GROUP=group)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_step_graph_replay_is_bitwise_the_eager_step(pkg, orc):
+    """gat_step captured into a hipGraph (launch-bound small graphs) replays the eager step exactly."""
+    A = pkg.abi
+    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 41, 300, 2500, (8, 8), (8, 8), 30, 5, hub=(7, 400), empty=(1, 2))
+    outs = []
+    for graph in (False, True):
+        ctx = pkg.GatContext(cfg.heads, cfg.outdims, cfg.in_dim0, cfg.num_classes)
+        ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
+        ctx.params_set(A.PARAM_W, W); ctx.params_set(A.PARAM_A, a); ctx.params_set(A.PARAM_WO, Wo)
+        if graph:
+            ctx.step_graph(True)
+        res = []
+        for it in range(4):                      # eager warm-up, capture, two replays
+            ctx.zero_grad()
+            loss, correct = ctx.step()
+            res.append((loss, correct, np.concatenate([ctx.grads_get(g) for g in range(3)])))
+            ctx.step_sgd(0.01)                   # parameters change between steps: the graph reads them by address
+        outs.append(res)
+        ctx.close()
+    for (l0, c0, g0), (l1, c1, g1) in zip(*outs):
+        assert l0 == l1 and c0 == c1 and np.array_equal(g0, g1)
+    ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+    assert abs(outs[1][0][0] - ref.loss_sum_f64) / 300 < TOL
+
+
+def test_step_graph_refused_with_timing(pkg):
+    ctx = pkg.GatContext([8, 8], [8, 8], 4, 3, collect_timing=True)
+    with pytest.raises(pkg.abi.GatError, match="collect_timing"):
+        ctx.step_graph(True)
+    ctx.close()
