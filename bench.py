@@ -90,6 +90,32 @@ def cpu_baseline(pkg, workload, heads, outdims, sample_scale):
     }
 
 
+def cpu_baseline_restructured(pkg, workload, heads, outdims):
+    """Second CPU line: the RESTRUCTURED algorithm — the one the HIP kernels implement — on the
+    host cores (oracle/gatv2_oracle.cpp::orc_step_restructured, OpenMP), on a same-law sample sized for
+    about 10 s.  A fairer comparison than the literal reference algorithm; still only a reported baseline."""
+    orc = entry.load_oracle()
+    n_full, e_full, f, c, kind = pkg.synth.SHAPES[workload]
+
+    def run(scale):
+        ds = pkg.synth.make_dataset(workload, scale=scale)
+        cfg = orc.Config(heads, outdims, ds["f"], ds["c"])
+        W, a, Wo = orc.xavier_params(cfg, 42)
+        t0 = time.perf_counter()
+        orc.step_restructured(cfg, ds["row_ptr"], ds["col_idx"], ds["labels"], ds["x"], W, a, Wo)
+        return ds, time.perf_counter() - t0
+
+    ds, t = run(min(1.0, max(200000.0 / e_full, 1e-3)))          # calibrate on ~200k edges
+    scale = min(1.0, 0.25, 10.0 * ds["e"] / (max(t, 1e-6) * e_full))
+    if scale * e_full > 2 * ds["e"]:
+        ds, t = run(scale)
+    return {
+        "value": ds["e"] / t, "unit": "edges/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
+        "sample": f"{workload}-law graph scaled to {ds['n']} nodes / {ds['e']} edges / {ds['f']} feat, 1 step fwd+bwd in "
+                  f"{t:.2f} s (restructured algorithm = the HIP path's, OpenMP; not the reference's kernels)",
+    }
+
+
 def measured_traffic(args, world, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/traffic.json,
     collected with tools/pmc_traffic.sh on this workload at N=1): PMC counters cannot be read from inside
@@ -268,6 +294,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pkg, args.workload, heads, outdims, args.cpu_sample_scale)
+            line["cpu_baseline_restructured"] = cpu_baseline_restructured(pkg, args.workload, heads, outdims)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     ctx.close()
     if dist is not None:

@@ -483,4 +483,214 @@ float orc_clip_grad_norm(float* grad, int64_t n, float thresh) {
     return norm;
 }
 
+
+// ---- restructured CPU step ---------------------------------------------------------------------------
+// NOT a restatement of the reference's kernels: the same ALGORITHM the HIP path uses (projections PL/PR
+// once per node, per-destination softmax, sum_k galpha_k alpha_k == <g, h_pre> for an O(E) softmax
+// backward, per-edge message rows summed source-major), OpenMP over rows.  bench.py times it as the
+// second, "fair" CPU line next to the literal one; tests check it against the literal
+// functions above.  Intended semantics (zeroed h_pre, per-head LReLU' index).  Returns 0.
+int orc_step_restructured(int L, const int* heads, const int* outdims, int F0, int C, int N, int E,
+                          const int* row_ptr, const int* col_idx, const int* labels, const float* X0,
+                          const float* W, const float* a, const float* Wo, float slope, double* loss_sum,
+                          int* n_correct, float* gradW, float* grada, float* gradWo) {
+    struct Lay { int H, D, HD, F; int64_t woff, aoff; std::vector<float> PL, PR, alpha, hpre, hout, g; };
+    std::vector<Lay> ly(L);
+    int64_t woff = 0, aoff = 0;
+    for (int l = 0; l < L; ++l) {
+        Lay& y = ly[l];
+        y.H = heads[l]; y.D = outdims[l]; y.HD = y.H * y.D; y.F = l == 0 ? F0 : ly[l - 1].HD;
+        y.woff = woff; y.aoff = aoff;
+        woff += (int64_t)y.HD * 2 * y.F; aoff += y.HD;
+    }
+    // source-major slot of every edge (stable: fixed summation order)
+    std::vector<int> sptr(N + 1, 0), pos(E);
+    for (int e = 0; e < E; ++e) sptr[col_idx[e] + 1]++;
+    for (int i = 0; i < N; ++i) sptr[i + 1] += sptr[i];
+    { std::vector<int> cur(sptr.begin(), sptr.end() - 1); for (int e = 0; e < E; ++e) pos[e] = cur[col_idx[e]]++; }
+
+    const float* Xin = X0;
+    for (int l = 0; l < L; ++l) {                                            // ---- forward
+        Lay& y = ly[l];
+        const int H = y.H, D = y.D, HD = y.HD, F = y.F;
+        const float* Wl = W + y.woff; const float* al = a + y.aoff;
+        const bool last = l == L - 1;
+        y.PL.assign((size_t)N * HD, 0.f); y.PR.assign((size_t)N * HD, 0.f);
+        y.alpha.assign((size_t)E * H, 0.f); y.hpre.assign((size_t)N * HD, 0.f);
+        y.hout.assign((size_t)N * (last ? D : HD), 0.f);
+#pragma omp parallel for schedule(static)
+        for (int n = 0; n < N; ++n) {
+            const float* x = Xin + (size_t)n * F;
+            for (int j = 0; j < HD; ++j) {
+                const float* w = Wl + (size_t)j * 2 * F;
+                float sl = 0.f, sr = 0.f;
+                for (int f = 0; f < F; ++f) { sl += w[f] * x[f]; sr += w[F + f] * x[f]; }
+                y.PL[(size_t)n * HD + j] = sl; y.PR[(size_t)n * HD + j] = sr;
+            }
+        }
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int n = 0; n < N; ++n) {
+            const int b = row_ptr[n], e_end = row_ptr[n + 1];
+            const float* pr = &y.PR[(size_t)n * HD];
+            float* hp = &y.hpre[(size_t)n * HD];
+            for (int h = 0; h < H; ++h) {
+                float m = -1e9f;                                             // E:336
+                for (int e = b; e < e_end; ++e) {
+                    const float* pl = &y.PL[(size_t)col_idx[e] * HD];
+                    float s = 0.f;
+                    for (int k = 0; k < D; ++k) s += al[h * D + k] * lrelu(pl[h * D + k] + pr[h * D + k], slope);
+                    y.alpha[(size_t)e * H + h] = s;
+                    m = std::max(m, s);
+                }
+                float Z = 0.f;
+                for (int e = b; e < e_end; ++e) Z += expf(y.alpha[(size_t)e * H + h] - m);
+                for (int e = b; e < e_end; ++e) {
+                    const float al_e = expf(y.alpha[(size_t)e * H + h] - m) / (Z + 1e-8f);      // E:378-379
+                    y.alpha[(size_t)e * H + h] = al_e;
+                    const float* pl = &y.PL[(size_t)col_idx[e] * HD];
+                    for (int k = 0; k < D; ++k) hp[h * D + k] += al_e * pl[h * D + k];
+                }
+            }
+            if (!last) for (int c = 0; c < HD; ++c) y.hout[(size_t)n * HD + c] = lrelu(hp[c], slope);
+            else for (int k = 0; k < D; ++k) {
+                float t = 0.f;
+                for (int h = 0; h < H; ++h) t += lrelu(hp[h * D + k], slope);
+                y.hout[(size_t)n * D + k] = t / (float)H;
+            }
+        }
+        Xin = y.hout.data();
+    }
+    // ---- output head, loss, and its backward (E:463-608)
+    Lay& yl = ly[L - 1];
+    const int DL = yl.D, HL = yl.H;
+    yl.g.assign((size_t)N * yl.HD, 0.f);
+    double loss = 0.0; long correct = 0;
+    const int T = orc_num_threads();
+    std::vector<std::vector<float>> pWo(T, std::vector<float>((size_t)C * DL, 0.f));
+#pragma omp parallel reduction(+ : loss, correct)
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num();
+#else
+        const int tid = 0;
+#endif
+        std::vector<float> z(C);
+#pragma omp for schedule(static)
+        for (int n = 0; n < N; ++n) {
+            const float* hl = &yl.hout[(size_t)n * DL];
+            float mv = -INFINITY;
+            for (int c = 0; c < C; ++c) {
+                float t = 0.f;
+                for (int d = 0; d < DL; ++d) t += Wo[c * DL + d] * hl[d];
+                z[c] = t; mv = std::max(mv, t);
+            }
+            float sum = 0.f;
+            for (int c = 0; c < C; ++c) { z[c] = expf(z[c] - mv); sum += z[c]; }
+            int pred = 0; float best = -1.f;
+            for (int c = 0; c < C; ++c) { z[c] = z[c] / (sum + 1e-8f); if (c == 0 || z[c] > best) { best = z[c]; pred = c; } }
+            loss += -logf(std::max(z[labels[n]], 1e-12f));
+            correct += pred == labels[n];
+            z[labels[n]] -= 1.0f;                                             // dz
+            for (int c = 0; c < C; ++c)
+                for (int d = 0; d < DL; ++d) pWo[tid][c * DL + d] += z[c] * hl[d];
+            for (int d = 0; d < DL; ++d) {
+                float gh = 0.f;
+                for (int c = 0; c < C; ++c) gh += Wo[c * DL + d] * z[c];
+                for (int h = 0; h < HL; ++h) {
+                    const size_t i = (size_t)n * yl.HD + h * DL + d;
+                    yl.g[i] = gh * dlrelu(yl.hpre[i], slope) / (float)HL;
+                }
+            }
+        }
+    }
+    for (int t = 0; t < T; ++t) for (int i = 0; i < C * DL; ++i) gradWo[i] += pWo[t][i];
+    *loss_sum = loss; *n_correct = (int)correct;
+
+    std::vector<float> msg, gPL, gPR;
+    for (int l = L - 1; l >= 0; --l) {                                       // ---- backward
+        Lay& y = ly[l];
+        const int H = y.H, D = y.D, HD = y.HD, F = y.F;
+        const float* Wl = W + y.woff; const float* al = a + y.aoff;
+        const float* X = l == 0 ? X0 : ly[l - 1].hout.data();
+        msg.assign((size_t)E * HD, 0.f); gPL.assign((size_t)N * HD, 0.f); gPR.assign((size_t)N * HD, 0.f);
+        std::vector<std::vector<float>> pa(T, std::vector<float>(HD, 0.f));
+#pragma omp parallel
+        {
+#ifdef _OPENMP
+            const int tid = omp_get_thread_num();
+#else
+            const int tid = 0;
+#endif
+#pragma omp for schedule(dynamic, 64)
+            for (int n = 0; n < N; ++n) {
+                const float* g = &y.g[(size_t)n * HD];
+                const float* pr = &y.PR[(size_t)n * HD];
+                float* gpr = &gPR[(size_t)n * HD];
+                for (int h = 0; h < H; ++h) {
+                    float dot = 0.f;
+                    for (int k = 0; k < D; ++k) dot += g[h * D + k] * y.hpre[(size_t)n * HD + h * D + k];
+                    for (int e = row_ptr[n]; e < row_ptr[n + 1]; ++e) {
+                        const float* pl = &y.PL[(size_t)col_idx[e] * HD];
+                        const float al_e = y.alpha[(size_t)e * H + h];
+                        float ga = 0.f;
+                        for (int k = 0; k < D; ++k) ga += g[h * D + k] * pl[h * D + k];
+                        const float ge = al_e * (ga - dot);
+                        float* m = &msg[(size_t)pos[e] * HD];
+                        for (int k = 0; k < D; ++k) {
+                            const int c = h * D + k;
+                            const float sv = pl[c] + pr[c];
+                            const float gs = ge * al[c] * dlrelu(sv, slope);
+                            pa[tid][c] += ge * lrelu(sv, slope);
+                            gpr[c] += gs;
+                            m[c] = g[c] * al_e + gs;
+                        }
+                    }
+                }
+            }
+#pragma omp for schedule(dynamic, 64)
+            for (int sidx = 0; sidx < N; ++sidx) {
+                float* o = &gPL[(size_t)sidx * HD];
+                for (int i = sptr[sidx]; i < sptr[sidx + 1]; ++i)
+                    for (int c = 0; c < HD; ++c) o[c] += msg[(size_t)i * HD + c];
+            }
+        }
+        for (int t = 0; t < T; ++t) for (int c = 0; c < HD; ++c) grada[y.aoff + c] += pa[t][c];
+        // gradW[j][0:F] += sum_n gPL[n][j] X[n][:],  [F:2F] with gPR  (thread-local slabs, summed in thread order)
+        std::vector<std::vector<float>> pw(T, std::vector<float>((size_t)HD * 2 * F, 0.f));
+#pragma omp parallel
+        {
+#ifdef _OPENMP
+            const int tid = omp_get_thread_num();
+#else
+            const int tid = 0;
+#endif
+            float* w = pw[tid].data();
+#pragma omp for schedule(static)
+            for (int n = 0; n < N; ++n) {
+                const float* x = X + (size_t)n * F;
+                for (int j = 0; j < HD; ++j) {
+                    const float gl = gPL[(size_t)n * HD + j], gr = gPR[(size_t)n * HD + j];
+                    float* wj = w + (size_t)j * 2 * F;
+                    for (int f = 0; f < F; ++f) { wj[f] += gl * x[f]; wj[F + f] += gr * x[f]; }
+                }
+            }
+        }
+        for (int t = 0; t < T; ++t) for (int64_t i = 0; i < (int64_t)HD * 2 * F; ++i) gradW[y.woff + i] += pw[t][i];
+        if (l > 0) {
+            Lay& yp = ly[l - 1];
+            yp.g.assign((size_t)N * yp.HD, 0.f);
+#pragma omp parallel for schedule(static)
+            for (int n = 0; n < N; ++n)
+                for (int f = 0; f < F; ++f) {
+                    float t = 0.f;
+                    for (int j = 0; j < HD; ++j)
+                        t += gPL[(size_t)n * HD + j] * Wl[(size_t)j * 2 * F + f] + gPR[(size_t)n * HD + j] * Wl[(size_t)j * 2 * F + F + f];
+                    yp.g[(size_t)n * F + f] = t * dlrelu(yp.hpre[(size_t)n * F + f], slope);
+                }
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"
+

@@ -61,6 +61,8 @@ def lib() -> C.CDLL:
         "orc_sgd": ([f32p, f32p, f, C.c_int64], None),
         "orc_adam": ([f32p, f32p, f32p, f32p, f, C.c_int64, f, f, f, i], None),
         "orc_clip_grad_norm": ([f32p, C.c_int64, f], f),
+        "orc_step_restructured": ([i, i32p, i32p, i, i, i, i, i32p, i32p, i32p, f32p, f32p, f32p, f32p, f,
+                                   C.POINTER(C.c_double), C.POINTER(i), f32p, f32p, f32p], i),
     }
     for name, (argt, rest) in sig.items():
         fn = getattr(L, name)
@@ -228,3 +230,22 @@ def step(cfg: Config, row_ptr, col_idx, labels, X0, W, a, Wo, *, flat_lrelu_inde
         Lb.orc_preact_gradient(N, NEG_SLOPE, F, taps["hpre"][l - 1].reshape(-1), g[l - 1])  # E:1546
     r.gradW, r.grada, r.gradWo = gradW, grada, gradWo
     return r
+
+
+def step_restructured(cfg: Config, row_ptr, col_idx, labels, X0, W, a, Wo):
+    """One forward + backward with the RESTRUCTURED algorithm (the one the HIP path uses) on the host
+    cores: bench.py's second CPU line; not a restatement of the reference's kernels.
+    -> (loss_sum, n_correct, gradW, grada, gradWo)"""
+    Lb = lib()
+    row_ptr = np.ascontiguousarray(row_ptr, np.int32); col_idx = np.ascontiguousarray(col_idx, np.int32)
+    labels = np.ascontiguousarray(labels, np.int32); X0 = np.ascontiguousarray(X0, np.float32)
+    W = np.ascontiguousarray(W, np.float32); a = np.ascontiguousarray(a, np.float32)
+    Wo = np.ascontiguousarray(Wo, np.float32)
+    heads = np.asarray(cfg.heads, np.int32); outdims = np.asarray(cfg.outdims, np.int32)
+    gW, ga, gWo = np.zeros_like(W), np.zeros_like(a), np.zeros_like(Wo)
+    loss, corr = C.c_double(), C.c_int()
+    rc = Lb.orc_step_restructured(cfg.L, heads, outdims, cfg.in_dim0, cfg.num_classes, len(row_ptr) - 1, len(col_idx),
+                                  row_ptr, col_idx, labels, X0, W, a, Wo, NEG_SLOPE, C.byref(loss), C.byref(corr),
+                                  gW, ga, gWo)
+    assert rc == 0
+    return loss.value, corr.value, gW, ga, gWo

@@ -122,3 +122,23 @@ def test_optimizer_and_clip(orc):
     m = np.zeros_like(p); v = np.zeros_like(p); p2 = p.copy()
     L.orc_adam(p2, g, m, v, 0.01, p2.size, 0.9, 0.999, 1e-8, 1)
     assert np.allclose(p2, p - 0.01 * np.sign(g), atol=1e-4)        # first Adam step == lr*sign(g)
+
+
+@pytest.mark.parametrize("heads,outdims", [((8, 8), (8, 8)), ((3, 1), (4, 5)), ((2, 2, 1), (4, 4, 8))])
+def test_restructured_cpu_step_matches_literal(orc, heads, outdims):
+    """bench.py's second CPU line (PL/PR projections, O(E) softmax backward, message rows summed
+    source-major — the HIP path's algorithm on host cores) against the literal restatement."""
+    from conftest import grad_close, small_graph
+    rng = np.random.default_rng(8)
+    n, f, c = 70, 9, 4
+    rp, ci = small_graph(rng, n, 500, hub=(3, 90), empty=(0, 11))
+    x = rng.standard_normal((n, f)).astype(np.float32)
+    lab = rng.integers(0, c, n).astype(np.int32); lab[0] = c - 1
+    cfg = orc.Config(list(heads), list(outdims), f, c)
+    W, a, Wo = orc.xavier_params(cfg, 2)
+    ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+    loss, correct, gW, ga, gWo = orc.step_restructured(cfg, rp, ci, lab, x, W, a, Wo)
+    assert abs(loss - ref.loss_sum_f64) < 1e-4 * n and correct == ref.n_correct
+    for got, want in ((gW, ref.gradW), (ga, ref.grada), (gWo, ref.gradWo)):
+        ok, info = grad_close(got, want, 1e-4, frac=0.02)
+        assert ok, info
