@@ -277,7 +277,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}-shape synthetic power-law graph, {n} nodes / {e} edges / {f} feat / "
-                            f"{c} classes, {len(heads)}-layer GATv2 heads {heads} outdims {outdims}, fp32",
+                            f"{c} classes, {len(heads)}-layer GATv2 heads {heads} outdims {outdims}, "
+                            + ("fp32" if args.dtype == "f32" else "fp32 arithmetic / bf16 PL+message storage"),
                 "launch": "hipGraph replay" if use_graph else "eager",
                 "parallelism": (f"dst-range x{world}, " + ("all layers exchanged" if args.exchange_layer0 else
                                 "input features replicated (layer 0 exchange-free)") + f", exchanges: {comm_kind}")

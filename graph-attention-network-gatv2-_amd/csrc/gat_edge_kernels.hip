@@ -444,9 +444,11 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
         const int64_t row = item.x;
         const int b = item.y, e_end = item.z, slot = item.w;
         const int e_end_v = per_lane(e_end);
-        const float g = A.g[row * HD + c];
+        const float hp = A.hpre[row * HD + c];
+        float g = A.g[row * HD + c];
+        if (A.g_raw) g *= hp > 0.f ? 1.0f : A.slope;             // E:888-892 applied by the consumer
         const float pr = A.PR[row * HD + c];
-        const float dot = group_sum<D>(g * A.hpre[row * HD + c]);
+        const float dot = group_sum<D>(g * hp);
         const float m2 = A.mstat[row * (HD / D) + c / D];
         const float inv = __builtin_amdgcn_rcpf(A.zstat[row * (HD / D) + c / D] + 1e-8f);
         float gpr = 0.f;
@@ -557,11 +559,15 @@ __global__ __launch_bounds__(64) void edge_bwd_generic(EdgeBwdArgs A) {
     const int lane = threadIdx.x;
     const float slope = A.slope;
     for (int ch = lane; ch < HD; ch += 64) s_ga[ch] = 0.f;
+    auto gval = [&](int64_t i) {                                  // dL/dh_pre (see EdgeBwdArgs::g_raw)
+        const float gv = A.g[i];
+        return A.g_raw ? gv * (A.hpre[i] > 0.f ? 1.0f : slope) : gv;
+    };
     for (int64_t row = blockIdx.x; row < A.n_rows; row += gridDim.x) {
         const int b = A.row_ptr[row], e_end = A.row_ptr[row + 1];
         for (int h = lane; h < H; h += 64) {
             float t = 0.f;
-            for (int k = 0; k < D; ++k) t += A.g[row * HD + h * D + k] * A.hpre[row * HD + h * D + k];
+            for (int k = 0; k < D; ++k) t += gval(row * HD + h * D + k) * A.hpre[row * HD + h * D + k];
             s_dot[h] = t;
         }
         for (int ch = lane; ch < HD; ch += 64) s_gpr[ch] = 0.f;
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(64) void edge_bwd_generic(EdgeBwdArgs A) {
             const int64_t sid = A.col_idx[e];
             for (int h = lane; h < H; h += 64) {
                 float t = 0.f;
-                for (int k = 0; k < D; ++k) t += A.g[row * HD + h * D + k] * A.PL[sid * HD + h * D + k];
+                for (int k = 0; k < D; ++k) t += gval(row * HD + h * D + k) * A.PL[sid * HD + h * D + k];
                 const float al = A.alpha[(int64_t)e * H + h];
                 const float ge = al * (t - s_dot[h]);
                 s_ge[h] = ge;
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(64) void edge_bwd_generic(EdgeBwdArgs A) {
                 const float gs = ge * A.a[ch] * (pos ? 1.0f : slope);
                 s_ga[ch] += ge * (pos ? s : s * slope);
                 s_gpr[ch] += gs;
-                unsafeAtomicAdd(A.gPL + sid * HD + ch, A.g[row * HD + ch] * s_al[ch / D] + gs);
+                unsafeAtomicAdd(A.gPL + sid * HD + ch, gval(row * HD + ch) * s_al[ch / D] + gs);
             }
             __syncthreads();
         }

@@ -94,6 +94,14 @@ struct EpiGradX {                 // g_prev = gX ⊙ LReLU'(h_pre_prev)   (E:888
     __device__ __forceinline__ void operator()(int64_t i, int j, float v) const { apply(i, j, v, pre(i, j)); }
 };
 
+struct EpiStore {                 // out[i][j] = v
+    static constexpr bool kTwoPhase = false;
+    float* out; int32_t ld;
+    __device__ __forceinline__ float pre(int64_t, int) const { return 0.f; }
+    __device__ __forceinline__ void apply(int64_t i, int j, float v, float) const { out[i * ld + j] = v; }
+    __device__ __forceinline__ void operator()(int64_t i, int j, float v) const { out[i * ld + j] = v; }
+};
+
 constexpr int kKC = 128;          // K chunk resident in LDS
 
 }  // namespace
@@ -376,8 +384,9 @@ int launch_grad_x(const float* gPL_rows, const float* gPR, const float* W, const
                   float* gprev, int64_t n_rows, int32_t F, int32_t HD, float slope, hipStream_t s) {
     ASrcGcat as{gPL_rows, gPR, HD};
     BSrcGradX bs{W, F, HD};
-    EpiGradX ep{gprev, hpre_prev, F, slope};
     const bool vec4 = (HD % 4 == 0) && aligned16(gPL_rows) && aligned16(gPR);
+    if (hpre_prev == nullptr) return run_rowgemm(as, bs, EpiStore{gprev, F}, n_rows, F, 2 * HD, vec4, s);
+    EpiGradX ep{gprev, hpre_prev, F, slope};
     return run_rowgemm(as, bs, ep, n_rows, F, 2 * HD, vec4, s);
 }
 

@@ -79,7 +79,9 @@ struct EdgeBwdArgs {
     const float* mstat;       // [n_rows][H] forward softmax max (fast path: log2 domain)
     const float* zstat;       // [n_rows][H] forward softmax sum
     const float* hpre;        // [n_rows][HD]
-    const float* g;           // [n_rows][HD]  dL/dh_pre
+    const float* g;           // [n_rows][HD]  dL/dh_pre — or, with g_raw, dL/d(layer output): the edge kernels then
+                              // apply LReLU'(h_pre) on load (E:888-892 folded into the consumer, which reads h_pre anyway)
+    int32_t g_raw;
     float* gPL;               // [n_table][HD]  atomics path only: zeroed by the caller, added into
     const int32_t* pos;       // [E] CSC slot of every edge, or null = atomics path
     float* msg;               // [E][HD] message rows by slot (store path; summed by launch_gpl_sum)
@@ -162,6 +164,7 @@ int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);
 int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float* gradW,
                   float* scratch, int64_t n_rows, int32_t F, int32_t HD, int32_t part, hipStream_t s);
 // gprev[n][f] = (sum_j gPL[n][j] W[j][f] + gPR[n][j] W[j][F+f]) * LReLU'(hpre_prev[n][f])
+// hpre_prev == nullptr: the plain sum is stored (the consumer applies LReLU', see EdgeBwdArgs::g_raw)
 int launch_grad_x(const float* gPL_rows, const float* gPR, const float* W, const float* hpre_prev,
                   float* gprev, int64_t n_rows, int32_t F, int32_t HD, float slope, hipStream_t s);
 
