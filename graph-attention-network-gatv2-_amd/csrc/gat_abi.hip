@@ -85,6 +85,7 @@ struct gat_ctx {
     int32_t HDmax = 0, Hmax = 0;
     float* gPL = nullptr; bool gPL_bound = false;   // [n_table][HDmax]
     float* gPR = nullptr;                           // [n_rows][HDmax]
+    float* gH = nullptr;                            // [n_rows][D_last] head-independent output gradient (HeadBwdArgs::gh_out)
     int32_t* csc_pos = nullptr;                     // [E] slot of each CSR edge in source-major order
     int32_t* csc_ptr = nullptr;                     // [n_table+1]
     float* msg = nullptr; int32_t msg_hd = 0;       // [E][msg_hd] per-edge message rows (store path)
@@ -194,13 +195,15 @@ static int ensure_buffers(gat_ctx* c) {
         if (c->cfg.keep_taps || !edge_fast_path(y.H, y.D, c->n_table)) GAT_TRY(dalloc(c, &y.alpha, E * y.H));
         GAT_TRY(dalloc(c, &y.hpre, N * y.HD));
         GAT_TRY(dalloc(c, &y.hout, N * (l == L - 1 ? y.D : y.HD)));
-        GAT_TRY(dalloc(c, &y.g, N * y.HD));
+        // the last layer's g is formed inside its edge backward from gH (except in the flat-index mode, E:598)
+        if (l < L - 1 || c->cfg.flat_lrelu_index) GAT_TRY(dalloc(c, &y.g, N * y.HD));
         GAT_TRY(dalloc(c, &y.mstat, N * y.H));
         GAT_TRY(dalloc(c, &y.zstat, N * y.H));
         if (c->cfg.keep_taps) GAT_TRY(dalloc(c, &y.ge, E * y.H));
     }
     if (!c->gPL_bound) GAT_TRY(dalloc(c, &c->gPL, T * c->HDmax));
     GAT_TRY(dalloc(c, &c->gPR, N * c->HDmax));
+    if (!c->cfg.flat_lrelu_index) GAT_TRY(dalloc(c, &c->gH, N * c->layers[L - 1].D));
     // work items (rows / hub-row segments) of the wave-per-item kernels
     GAT_TRY(dalloc(c, &c->items, std::max<int64_t>(c->work.n_items, 1)));
     GAT_TRY(dalloc(c, &c->slot_info, std::max<int32_t>(c->work.n_slots, 1)));
@@ -590,7 +593,7 @@ int gat_head_backward(gat_ctx* c) {
     GAT_TRY(check_layer(c, 0));
     const Layer& y = c->layers.back();
     HeadBwdArgs a{};
-    a.Wo = Wo_of(c); a.HL = y.hout; a.y = c->y; a.labels = c->labels; a.hpre = y.hpre; a.g = y.g;
+    a.Wo = Wo_of(c); a.HL = y.hout; a.y = c->y; a.labels = c->labels; a.hpre = y.hpre; a.g = y.g; a.gh_out = c->gH;
     a.gradWo = gWo_of(c); a.partial = c->hb_partial; a.n_rows = c->n_rows; a.C = c->cfg.num_classes;
     a.DL = y.D; a.H = y.H; a.slope = c->cfg.negative_slope; a.flat_index = c->cfg.flat_lrelu_index;
     Scope t(c, GAT_K_HEAD_BWD);
@@ -610,6 +613,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.alpha = y.alpha; a.mstat = y.mstat; a.zstat = y.zstat;
     a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge;
     a.g_raw = l < c->cfg.num_layers - 1;           // hidden layers: written by launch_grad_x without the LReLU' factor
+    a.gh = (l == c->cfg.num_layers - 1) ? c->gH : nullptr;
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
     a.part_acc = c->part_acc;
@@ -932,6 +936,16 @@ int gat_tap(gat_ctx* c, int tensor, int32_t l, void* host, int64_t count) {
         case GAT_TAP_Y: GAT_TRY(need(N * c->cfg.num_classes)); return d2h(c, host, c->y, N * c->cfg.num_classes * sizeof(float));
         case GAT_TAP_G: {
             GAT_TRY(need(N * y.HD));
+            if (last && c->gH) {                        // formed on the fly by the kernels: same expression, same order
+                std::vector<float> hp((size_t)(N * y.HD)), gh((size_t)(N * y.D));
+                GAT_TRY(d2h(c, hp.data(), y.hpre, hp.size() * sizeof(float)));
+                GAT_TRY(d2h(c, gh.data(), c->gH, gh.size() * sizeof(float)));
+                float* out = static_cast<float*>(host);
+                const float inv_heads = 1.0f / (float)y.H;
+                for (int64_t i = 0; i < N * y.HD; ++i)
+                    out[i] = gh[(size_t)((i / y.HD) * y.D + i % y.D)] * (hp[(size_t)i] > 0.f ? 1.0f : c->cfg.negative_slope) * inv_heads;
+                return 0;
+            }
             GAT_TRY(d2h(c, host, y.g, N * y.HD * sizeof(float)));
             if (l < c->cfg.num_layers - 1) {         // stored without the LReLU'(h_pre) factor (EdgeBwdArgs::g_raw)
                 std::vector<float> hp((size_t)(N * y.HD));

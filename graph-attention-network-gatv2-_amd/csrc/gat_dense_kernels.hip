@@ -213,7 +213,9 @@ __global__ __launch_bounds__(256) void head_backward_kernel(HeadBwdArgs A, int32
             }
         }
         __syncthreads();
-        {
+        if (A.gh_out != nullptr)
+            for (int q = threadIdx.x; q < rows_here * DL; q += 256) A.gh_out[n0 * DL + q] = s_gh[q];
+        if (A.g != nullptr) {
             const float* hp = A.hpre + n0 * hd;
             float* gt = A.g + n0 * hd;
             int r = threadIdx.x / hd, x = threadIdx.x % hd;     // x = h*DL + d

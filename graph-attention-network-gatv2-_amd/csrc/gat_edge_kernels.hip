@@ -445,8 +445,12 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
         const int b = item.y, e_end = item.z, slot = item.w;
         const int e_end_v = per_lane(e_end);
         const float hp = A.hpre[row * HD + c];
-        float g = A.g[row * HD + c];
-        if (A.g_raw) g *= hp > 0.f ? 1.0f : A.slope;             // E:888-892 applied by the consumer
+        float g;
+        if (A.gh != nullptr) g = A.gh[row * D + (c % D)] * (hp > 0.f ? 1.0f : A.slope) * (1.0f / (float)(HD / D));   // E:598-603
+        else {
+            g = A.g[row * HD + c];
+            if (A.g_raw) g *= hp > 0.f ? 1.0f : A.slope;         // E:888-892 applied by the consumer
+        }
         const float pr = A.PR[row * HD + c];
         const float dot = group_sum<D>(g * hp);
         const float m2 = A.mstat[row * (HD / D) + c / D];
@@ -560,6 +564,7 @@ __global__ __launch_bounds__(64) void edge_bwd_generic(EdgeBwdArgs A) {
     const float slope = A.slope;
     for (int ch = lane; ch < HD; ch += 64) s_ga[ch] = 0.f;
     auto gval = [&](int64_t i) {                                  // dL/dh_pre (see EdgeBwdArgs::g_raw)
+        if (A.gh != nullptr) return A.gh[(i / HD) * D + (i % D)] * (A.hpre[i] > 0.f ? 1.0f : slope) * (1.0f / (float)H);
         const float gv = A.g[i];
         return A.g_raw ? gv * (A.hpre[i] > 0.f ? 1.0f : slope) : gv;
     };

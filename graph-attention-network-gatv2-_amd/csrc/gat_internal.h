@@ -82,6 +82,8 @@ struct EdgeBwdArgs {
     const float* g;           // [n_rows][HD]  dL/dh_pre — or, with g_raw, dL/d(layer output): the edge kernels then
                               // apply LReLU'(h_pre) on load (E:888-892 folded into the consumer, which reads h_pre anyway)
     int32_t g_raw;
+    const float* gh;          // last layer, or null: [n_rows][D] head-independent output gradient; the kernels form
+                              // g[n,h,d] = gh[n,d] * LReLU'(h_pre[n,h,d]) / H themselves (E:598-603) and ignore `g`
     float* gPL;               // [n_table][HD]  atomics path only: zeroed by the caller, added into
     const int32_t* pos;       // [E] CSC slot of every edge, or null = atomics path
     float* msg;               // [E][HD] message rows by slot (store path; summed by launch_gpl_sum)
@@ -189,7 +191,9 @@ struct HeadBwdArgs {
     const float* y;           // [n_rows][C]
     const int32_t* labels;
     const float* hpre;        // last layer pre-activation [n_rows][H][DL]
-    float* g;                 // [n_rows][H][DL]
+    float* g;                 // [n_rows][H][DL], or null: only gh_out is written and the edge backward of the last
+                              // layer expands it (EdgeBwdArgs::gh) — saves writing 4*N*H*D and reading h_pre here
+    float* gh_out;            // [n_rows][DL]  Wo^T dz  (the head-independent part of g), or null
     float* gradWo;            // [C][DL] added into
     float* partial;           // [head_bwd_blocks][C*DL]
     int64_t n_rows;
