@@ -88,6 +88,8 @@ struct gat_ctx {
     float* gH = nullptr;                            // [n_rows][D_last] head-independent output gradient (HeadBwdArgs::gh_out)
     int32_t* csc_pos = nullptr;                     // [E] slot of each CSR edge in source-major order
     int32_t* csc_ptr = nullptr;                     // [n_table+1]
+    int4* gpl_chunks = nullptr; int4* gpl_heavy = nullptr; float* gpl_part = nullptr;   // long source lists (HeavyList)
+    int32_t n_gpl_chunks = 0, n_gpl_heavy = 0;
     float* msg = nullptr; int32_t msg_hd = 0;       // [E][msg_hd] per-edge message rows (store path)
     int32_t dbg = 0;                                // GAT_DBG timing experiments (0 = product behaviour)
     gat::WorkList work;                             // host copy of the item list
@@ -230,6 +232,17 @@ static int ensure_buffers(gat_ctx* c) {
             GAT_TRY(dalloc(c, &c->csc_pos, E));
             GAT_TRY(dalloc(c, &c->csc_ptr, T + 1));
             GAT_TRY(build_csc(c->col_idx, E, T, c->csc_pos, c->csc_ptr, c->stream));
+            HeavyList hl;
+            GAT_TRY(build_heavy_list(c->csc_ptr, T, &hl, c->stream));
+            c->n_gpl_chunks = (int32_t)(hl.chunks.size() / 4); c->n_gpl_heavy = (int32_t)(hl.heavy.size() / 4);
+            if (c->n_gpl_heavy > 0) {
+                GAT_TRY(dalloc(c, &c->gpl_chunks, c->n_gpl_chunks));
+                GAT_TRY(dalloc(c, &c->gpl_heavy, c->n_gpl_heavy));
+                GAT_TRY(dalloc(c, &c->gpl_part, (int64_t)c->n_gpl_chunks * msg_hd));
+                GAT_HIP(hipMemcpyAsync(c->gpl_chunks, hl.chunks.data(), hl.chunks.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                GAT_HIP(hipMemcpyAsync(c->gpl_heavy, hl.heavy.data(), hl.heavy.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                GAT_HIP(hipStreamSynchronize(c->stream));
+            }
         } else {
             (void)hipGetLastError();      // not enough HBM for the scratch: atomics variant
         }
@@ -628,7 +641,8 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     }
     if (store) {
         Scope t(c, GAT_K_GPL_SUM);
-        GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, bf16(c), c->stream));
+        GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, bf16(c), c->gpl_chunks, c->n_gpl_chunks,
+                               c->gpl_heavy, c->n_gpl_heavy, c->gpl_part, c->stream));
     }
     Scope t(c, GAT_K_MISC);
     return launch_reduce_partials_add(c->ga_partial, a.ga_blocks, y.HD, ga_of(c, l), c->stream);

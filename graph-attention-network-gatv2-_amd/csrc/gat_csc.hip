@@ -38,12 +38,102 @@ __global__ __launch_bounds__(256) void segment_offsets_kernel(const int32_t* __r
     }
 }
 
+// Sources with more than kHeavySlots slots (power-law hubs: one wave would stream megabytes with a few KB in
+// flight and become the tail of the launch — 13 k slots = 1.7 ms alone) are cut into chunks of kHeavySlots,
+// one wave each, partial rows summed per source in chunk order by a small second kernel (deterministic).
+constexpr int kHeavySlotsDefault = 256;
+static int heavy_slots() {                              // GAT_GPL_HEAVY=<n> overrides (tests: huge = never chunk)
+    static const int v = [] { const char* e = getenv("GAT_GPL_HEAVY"); const int x = e ? atoi(e) : 0; return x > 0 ? x : kHeavySlotsDefault; }();
+    return v;
+}
+
+// chunks: {first slot, end slot, partial row index, -}; row = HD floats (BF: HD bf16) per slot
+template <int HD, bool BF>
+__global__ __launch_bounds__(256) void gpl_chunk_kernel(const int4* __restrict__ chunks, int32_t n_chunks,
+                                                        const float* __restrict__ msg, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= n_chunks) return;
+    const int4 ch = chunks[k];
+    const int b = ch.x, e = ch.y;
+    constexpr int U = 8;
+    if constexpr (!BF) {
+        constexpr int LPR = HD / 4, RPI = 64 / LPR;
+        const int q = lane % LPR, r = lane / LPR;
+        const float4* m4 = reinterpret_cast<const float4*>(msg);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i0 = b; i0 < e; i0 += RPI * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * RPI + r;
+                v[u] = (i < e) ? m4[(int64_t)i * LPR + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+        }
+        if (r == 0) reinterpret_cast<float4*>(part)[(int64_t)ch.z * LPR + q] = acc;
+    } else {
+        constexpr int LPR = HD / 8, RPI = 64 / LPR;
+        const int q = lane % LPR, r = lane / LPR;
+        const uint4* m8 = reinterpret_cast<const uint4*>(msg);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int i0 = b; i0 < e; i0 += RPI * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * RPI + r;
+                v[u] = (i < e) ? m8[(int64_t)i * LPR + q] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * j] += __builtin_bit_cast(float, w[j] << 16);
+                    acc[2 * j + 1] += __builtin_bit_cast(float, w[j] & 0xFFFF0000u);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off);
+        if (r == 0) {
+            float4* out = reinterpret_cast<float4*>(part + (int64_t)ch.z * HD + q * 8);
+            out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+}
+// heavy: {source, first partial, partial count, -}; one thread per (source, channel), ascending chunk order
+__global__ __launch_bounds__(256) void gpl_heavy_fix_kernel(const int4* __restrict__ heavy, int32_t n_heavy,
+                                                            const float* __restrict__ part, float* __restrict__ gPL,
+                                                            int32_t HD) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t k = t / HD;
+    const int c = (int)(t % HD);
+    if (k >= n_heavy) return;
+    const int4 h = heavy[k];
+    float s = 0.f;
+    for (int p = h.y; p < h.y + h.z; ++p) s += part[(int64_t)p * HD + c];
+    gPL[(int64_t)h.x * HD + c] = s;
+}
+
 // gPL[s][:] = sum over slots of s.  Row = HD floats read as float4 by HD/4 lanes, 64/(HD/4) rows
 // per wave-instruction (1 KiB), U instructions in flight.
 template <int HD>
 __global__ __launch_bounds__(256) void gpl_sum_kernel(const int32_t* __restrict__ src_ptr,
                                                       const float* __restrict__ msg, float* __restrict__ gPL,
-                                                      int64_t n_table) {
+                                                      int64_t n_table, int32_t kHeavySlots) {
     constexpr int LPR = HD / 4;          // lanes per row
     constexpr int RPI = 64 / LPR;        // rows per wave-instruction
     constexpr int U = 4;
@@ -52,6 +142,7 @@ __global__ __launch_bounds__(256) void gpl_sum_kernel(const int32_t* __restrict_
     const int64_t s = (int64_t)blockIdx.x * 4 + wave;
     if (s >= n_table) return;
     const int b = src_ptr[s], e = src_ptr[s + 1];
+    if (e - b > kHeavySlots) return;                    // long lists: gpl_chunk_kernel + gpl_heavy_fix_kernel
     const int q = lane % LPR, r = lane / LPR;
     const float4* m4 = reinterpret_cast<const float4*>(msg);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -79,7 +170,7 @@ __global__ __launch_bounds__(256) void gpl_sum_kernel(const int32_t* __restrict_
 template <int HD>
 __global__ __launch_bounds__(256) void gpl_sum_bf16_kernel(const int32_t* __restrict__ src_ptr,
                                                            const float* __restrict__ msg, float* __restrict__ gPL,
-                                                           int64_t n_table) {
+                                                           int64_t n_table, int32_t kHeavySlots) {
     constexpr int LPR = HD / 8, RPI = 64 / LPR, U = 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -87,6 +178,7 @@ __global__ __launch_bounds__(256) void gpl_sum_bf16_kernel(const int32_t* __rest
     const int64_t s = (int64_t)blockIdx.x * 4 + wave;
     if (s >= n_table) return;
     const int b = src_ptr[s], e = src_ptr[s + 1];
+    if (e - b > kHeavySlots) return;
     const uint4* m8 = reinterpret_cast<const uint4*>(msg);
     float acc[8];
 #pragma unroll
@@ -127,7 +219,7 @@ constexpr int kGroupMax = 32;
 template <int HD>
 __global__ __launch_bounds__(256) void gpl_sum_group_kernel(const int32_t* __restrict__ src_ptr,
                                                             const float* __restrict__ msg, float* __restrict__ gPL,
-                                                            int64_t n_table) {
+                                                            int64_t n_table, int32_t kHeavySlots) {
     constexpr int LPR = HD / 4, RPI = 64 / LPR, U = 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -135,10 +227,11 @@ __global__ __launch_bounds__(256) void gpl_sum_group_kernel(const int32_t* __res
     const int64_t s = ((int64_t)blockIdx.x * 4 + wave) * RPI + r;
     int b = 0, e = 0;
     if (s < n_table) { b = src_ptr[s]; e = src_ptr[s + 1]; }
-    const bool big = (e - b) > kGroupMax;
+    const bool heavy = (e - b) > kHeavySlots;          // handled by gpl_chunk_kernel + gpl_heavy_fix_kernel
+    const bool big = !heavy && (e - b) > kGroupMax;
     const float4* m4 = reinterpret_cast<const float4*>(msg);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!big) {
+    if (!big && !heavy) {
         for (int i0 = b; i0 < e; i0 += U) {
             float4 v[U];
 #pragma unroll
@@ -171,7 +264,7 @@ __global__ __launch_bounds__(256) void gpl_sum_group_kernel(const int32_t* __res
         }
         if (r == g) acc = t;
     }
-    if (s < n_table) reinterpret_cast<float4*>(gPL)[s * LPR + q] = acc;
+    if (s < n_table && !heavy) reinterpret_cast<float4*>(gPL)[s * LPR + q] = acc;
 }
 
 }  // namespace
@@ -211,16 +304,57 @@ int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t*
     return rc;
 }
 
-int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
-                   int32_t HD, bool msg_bf16, hipStream_t s) {
+int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, HeavyList* out, hipStream_t s) {
+    out->chunks.clear(); out->heavy.clear();
     if (n_table <= 0) return 0;
+    std::vector<int32_t> ptr((size_t)n_table + 1);
+    GAT_HIP(hipMemcpyAsync(ptr.data(), d_src_ptr, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    GAT_HIP(hipStreamSynchronize(s));
+    const int kHeavySlots = heavy_slots();
+    for (int64_t src = 0; src < n_table; ++src) {
+        const int32_t b = ptr[(size_t)src], e = ptr[(size_t)src + 1];
+        if (e - b <= kHeavySlots) continue;
+        const int32_t first = (int32_t)(out->chunks.size() / 4);
+        int32_t n = 0;
+        for (int32_t cb = b; cb < e; cb += kHeavySlots, ++n)
+            out->chunks.insert(out->chunks.end(), {cb, std::min(e, cb + kHeavySlots), first + n, 0});
+        out->heavy.insert(out->heavy.end(), {(int32_t)src, first, n, 0});
+    }
+    return 0;
+}
+
+template <int HD>
+static int run_heavy(const float* msg, float* gPL, bool bf, const int4* chunks, int32_t n_chunks, const int4* heavy,
+                     int32_t n_heavy, float* part, hipStream_t s) {
+    const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
+    if (bf) hipLaunchKernelGGL((gpl_chunk_kernel<HD, true>), grid, block, 0, s, chunks, n_chunks, msg, part);
+    else hipLaunchKernelGGL((gpl_chunk_kernel<HD, false>), grid, block, 0, s, chunks, n_chunks, msg, part);
+    const int64_t threads = (int64_t)n_heavy * HD;
+    hipLaunchKernelGGL(gpl_heavy_fix_kernel, dim3((unsigned)((threads + 255) / 256)), block, 0, s, heavy, n_heavy, part, gPL, HD);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
+                   int32_t HD, bool msg_bf16, const int4* chunks, int32_t n_chunks, const int4* heavy,
+                   int32_t n_heavy, float* part, hipStream_t s) {
+    if (n_table <= 0) return 0;
+    if (n_heavy > 0) {                                  // long lists first: they are the longest-running waves
+        switch (HD) {
+            case 64: GAT_TRY(run_heavy<64>(msg, gPL, msg_bf16, chunks, n_chunks, heavy, n_heavy, part, s)); break;
+            case 32: GAT_TRY(run_heavy<32>(msg, gPL, msg_bf16, chunks, n_chunks, heavy, n_heavy, part, s)); break;
+            case 16: GAT_TRY(run_heavy<16>(msg, gPL, msg_bf16, chunks, n_chunks, heavy, n_heavy, part, s)); break;
+            case 8: GAT_TRY(run_heavy<8>(msg, gPL, msg_bf16, chunks, n_chunks, heavy, n_heavy, part, s)); break;
+            default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
+        }
+    }
     if (msg_bf16) {
         const dim3 grid((unsigned)((n_table + 3) / 4)), block(256);
         switch (HD) {
-            case 64: hipLaunchKernelGGL(gpl_sum_bf16_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
-            case 32: hipLaunchKernelGGL(gpl_sum_bf16_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
-            case 16: hipLaunchKernelGGL(gpl_sum_bf16_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
-            case 8: hipLaunchKernelGGL(gpl_sum_bf16_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+            case 64: hipLaunchKernelGGL(gpl_sum_bf16_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+            case 32: hipLaunchKernelGGL(gpl_sum_bf16_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+            case 16: hipLaunchKernelGGL(gpl_sum_bf16_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+            case 8: hipLaunchKernelGGL(gpl_sum_bf16_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
             default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
         }
         GAT_HIP(hipGetLastError());
@@ -232,10 +366,10 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
         const int rpi = 64 / (HD / 4);
         const dim3 grid((unsigned)((n_table + 4 * rpi - 1) / (4 * rpi))), block(256);
         switch (HD) {
-            case 64: hipLaunchKernelGGL(gpl_sum_group_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
-            case 32: hipLaunchKernelGGL(gpl_sum_group_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
-            case 16: hipLaunchKernelGGL(gpl_sum_group_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
-            case 8: hipLaunchKernelGGL(gpl_sum_group_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+            case 64: hipLaunchKernelGGL(gpl_sum_group_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+            case 32: hipLaunchKernelGGL(gpl_sum_group_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+            case 16: hipLaunchKernelGGL(gpl_sum_group_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+            case 8: hipLaunchKernelGGL(gpl_sum_group_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
             default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
         }
         GAT_HIP(hipGetLastError());
@@ -243,10 +377,10 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
     }
     const dim3 grid((unsigned)((n_table + 3) / 4)), block(256);
     switch (HD) {
-        case 64: hipLaunchKernelGGL(gpl_sum_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
-        case 32: hipLaunchKernelGGL(gpl_sum_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
-        case 16: hipLaunchKernelGGL(gpl_sum_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
-        case 8: hipLaunchKernelGGL(gpl_sum_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table); break;
+        case 64: hipLaunchKernelGGL(gpl_sum_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+        case 32: hipLaunchKernelGGL(gpl_sum_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+        case 16: hipLaunchKernelGGL(gpl_sum_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+        case 8: hipLaunchKernelGGL(gpl_sum_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
         default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
     }
     GAT_HIP(hipGetLastError());

@@ -113,8 +113,15 @@ bool edge_fast_path(int32_t H, int32_t D, int64_t n_table);
 // ---- source-major slot index + segmented sum (gat_csc.hip) ----------------------------------------
 int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t* pos, int32_t* src_ptr,
               hipStream_t s);
+// sources with long slot lists, cut into chunks (gat_csc.hip kHeavySlots): built once per graph from the CSC pointers
+struct HeavyList {
+    std::vector<int32_t> chunks;    // int4 {first slot, end slot, partial row, -}
+    std::vector<int32_t> heavy;     // int4 {source, first partial, partial count, -}
+};
+int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, HeavyList* out, hipStream_t s);
 int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
-                   int32_t HD, bool msg_bf16, hipStream_t s);
+                   int32_t HD, bool msg_bf16, const int4* chunks, int32_t n_chunks, const int4* heavy,
+                   int32_t n_heavy, float* part, hipStream_t s);
 
 int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);

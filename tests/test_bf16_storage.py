@@ -83,3 +83,44 @@ def test_bf16_sharded_two_processes_host_transport(pkg, orc, tmp_path):
     ref = [float(m.group(1)) for m in re.finditer(r"Avg Loss: ([0-9.]+)", f32.stdout)]
     for a, b, c in zip(outs[0], outs[1], ref):
         assert abs(a - b) < 1e-3 and abs(a - c) < TOL * max(1.0, c)
+
+
+def test_bf16_heavy_source_chunks_equal_unchunked(tmp_path):
+    """A source with ~400 slots takes the chunked message sum (kHeavySlots = 256).  Same run with chunking
+    disabled (GAT_GPL_HEAVY huge): the gradients may differ only by fp32 summation order."""
+    import sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, "tests")!r})
+        import __graft_entry__ as entry
+        from conftest import small_graph
+        pkg = entry.load_package(); orc = entry.load_oracle()
+        rng = np.random.default_rng(3)
+        rp, ci = small_graph(rng, 200, 1600, hub=(3, 300), empty=(0, 7))
+        ci = ci.copy(); ci[::4] = 11
+        for r in range(200): ci[rp[r]:rp[r + 1]].sort()
+        assert (ci == 11).sum() > 256
+        x = rng.standard_normal((200, 16)).astype(np.float32)
+        lab = rng.integers(0, 5, 200).astype(np.int32); lab[0] = 4
+        out = []
+        for dtype in ("bf16", "f32"):
+            for heads in ([8, 8], [4, 4]):
+                cfg = orc.Config(heads, [8, 8], 16, 5)
+                W, a, Wo = orc.xavier_params(cfg, 4)
+                ctx = pkg.GatContext(heads, [8, 8], 16, 5, dtype=dtype)
+                ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
+                for g, arr in enumerate((W, a, Wo)): ctx.params_set(g, arr)
+                ctx.zero_grad(); ctx.forward(); ctx.backward()
+                out.append(np.concatenate([ctx.grads_get(g) for g in range(3)]))
+                ctx.close()
+        np.save(sys.argv[1], np.concatenate(out))
+    """)
+    res = []
+    for tag, heavy in (("chunked", "256"), ("flat", "1000000000")):
+        f = str(tmp_path / f"{tag}.npy")
+        env = dict(os.environ, GAT_GPL_HEAVY=heavy)
+        r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(f))
+    assert np.abs(res[0] - res[1]).max() <= 1e-5 * np.abs(res[1]).max()

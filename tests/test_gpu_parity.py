@@ -232,7 +232,7 @@ def test_wide_heads_generic_path(pkg, orc):
 def test_source_hub_both_gpl_sum_variants(pkg, orc, group, monkeypatch):
     """A source with hundreds of out-edges among short lists: the source-major sum's wave-per-source
     kernel and its group-per-source variant (shards: ~deg/P slots per source; big lists handed to
-    the whole wave) must both match the oracle."""
+    the whole wave), and the chunked path for lists beyond kHeavySlots, must all match the oracle."""
     import subprocess, sys, textwrap
     # GAT_GPL_GROUP is read once per process: run each variant in its own interpreter
     code = textwrap.dedent(f"""
@@ -243,7 +243,7 @@ def test_source_hub_both_gpl_sum_variants(pkg, orc, group, monkeypatch):
         from conftest import grad_close
         pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
         rng = np.random.default_rng(17)
-        n = 240
+        n = 640          # source 3 is in every row: 640 slots = 3 chunks of the heavy-source path (kHeavySlots = 256)
         rows = [np.unique(np.concatenate([[3] if i % 4 else [3, 7], rng.integers(0, n, rng.integers(0, 6))])) for i in range(n)]
         rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
         ci = np.concatenate(rows).astype(np.int32)
