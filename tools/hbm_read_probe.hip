@@ -91,6 +91,42 @@ __global__ __launch_bounds__(256) void csc_sum_persistent(const int* __restrict_
         s = sn; b = bn; e = en;
     }
 }
+// 4 consecutive sources per wave: bounds fetched with one load, the first batch (<= 16 rows) of ALL four lists issued
+// before any is reduced; longer lists continue with the plain loop
+__global__ __launch_bounds__(256) void csc_sum4(const int* __restrict__ ptr, const float4* __restrict__ m4, float4* __restrict__ out, long n) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long s0 = ((long)blockIdx.x * 4 + wave) * 4;
+    if (s0 >= n) return;
+    const int q = lane & 15, r = lane >> 4;
+    int pv = 0;
+    if (lane < 5) pv = ptr[s0 + lane < n ? s0 + lane : n];
+    int p[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) p[k] = __builtin_amdgcn_readlane(pv, k);
+    float4 v[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = p[k] + u * 4 + r; v[k][u] = i < p[k + 1] ? m4[(size_t)i * 16 + q] : make_float4(0, 0, 0, 0); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += v[k][u].x; acc.y += v[k][u].y; acc.z += v[k][u].z; acc.w += v[k][u].w; }
+        for (int i0 = p[k] + 16; i0 < p[k + 1]; i0 += 16) {
+            float4 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = i0 + u * 4 + r; w[u] = i < p[k + 1] ? m4[(size_t)i * 16 + q] : make_float4(0, 0, 0, 0); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x += w[u].x; acc.y += w[u].y; acc.z += w[u].z; acc.w += w[u].w; }
+        }
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+        }
+        if (r == 0 && s0 + k < n) out[(s0 + k) * 16 + q] = acc;
+    }
+}
 template <class F> float timeit(F f) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -113,31 +149,39 @@ int main() {
         printf("wave/segment rows=%3d  U=4 %.2f ms %.2f TB/s | U=8 %.2f ms %.2f TB/s\n", rows, m4, bytes / m4 / 1e9, m8, bytes / m8 / 1e9);
     }
     // CSC-shaped: n sources, E slots; uniform lengths, then a power-law like the benchmark graph's out-degrees
-    const long n = 2450000, E = (long)(bytes / 256);
-    float4* out4; CK(hipMalloc(&out4, n * 256));
-    int* dptr; CK(hipMalloc(&dptr, (n + 1) * 4));
-    std::vector<int> hp(n + 1);
-    for (int mode = 0; mode < 2; ++mode) {
-        std::vector<double> w(n);
+    const long n0 = 2450000, E = (long)(bytes / 256);
+    float4* out4; CK(hipMalloc(&out4, (n0 + 100000) * 256));
+    int* dptr; CK(hipMalloc(&dptr, (n0 + 100001) * 4));
+    std::vector<int> hp(n0 + 1);
+    for (int mode = 0; mode < 3; ++mode) {
+        hp.assign(n0 + 1, 0);
+        std::vector<double> w(n0);
         double tot = 0;
         unsigned long long st = 88172645463325252ull;
-        for (long i = 0; i < n; ++i) {
+        for (long i = 0; i < n0; ++i) {
             st ^= st << 13; st ^= st >> 7; st ^= st << 17;                     // random placement of the heavy sources
-            const double rank = (double)(st % (unsigned long long)n);
+            const double rank = (double)(st % (unsigned long long)n0);
             w[i] = mode == 0 ? 1.0 : pow(rank + 100.0, -0.75);
             tot += w[i];
         }
         double accw = 0; hp[0] = 0;
-        for (long i = 0; i < n; ++i) { accw += w[i]; hp[i + 1] = (int)(accw / tot * (double)E); }
+        for (long i = 0; i < n0; ++i) { accw += w[i]; hp[i + 1] = (int)(accw / tot * (double)E); }
+        if (mode == 2) {                                     // power-law with the long lists cut at 256 (as gpl_sum does)
+            std::vector<int> cut; cut.push_back(0);
+            for (long i = 0; i < n0; ++i) { int b = hp[i]; const int e = hp[i + 1]; while (e - b > 256) { b += 256; cut.push_back(b); } cut.push_back(e); }
+            hp = cut;
+        }
+        const long n = (long)hp.size() - 1;
         CK(hipMemcpy(dptr, hp.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+        const float c4 = timeit([&] { csc_sum4<<<(unsigned)((n + 15) / 16), 256>>>(dptr, x, out4, n); });
         int mx = 0; for (long i = 0; i < n; ++i) mx = hp[i + 1] - hp[i] > mx ? hp[i + 1] - hp[i] : mx;
         const unsigned g = (unsigned)((n + 3) / 4);
         float a4 = timeit([&] { csc_sum<4><<<g, 256>>>(dptr, x, out4, n); });
         float a8 = timeit([&] { csc_sum<8><<<g, 256>>>(dptr, x, out4, n); });
         float p4 = timeit([&] { csc_sum_persistent<4><<<2048, 256>>>(dptr, x, out4, n); });
         float p8 = timeit([&] { csc_sum_persistent<4><<<4096, 256>>>(dptr, x, out4, n); });
-        printf("csc %s (max len %d): wave/source U=4 %.2f ms  U=8 %.2f ms | persistent 2048 blocks %.2f ms, 4096 blocks %.2f ms\n",
-               mode == 0 ? "uniform  " : "power-law", mx, a4, a8, p4, p8);
+        printf("csc %s (max len %d): wave/source U=4 %.2f ms  U=8 %.2f ms | persistent 2048 blocks %.2f ms, 4096 blocks %.2f ms | 4 sources/wave %.2f ms\n",
+               mode == 0 ? "uniform  " : mode == 1 ? "power-law" : "pl cut256", mx, a4, a8, p4, p8, c4);
     }
     return 0;
 }
