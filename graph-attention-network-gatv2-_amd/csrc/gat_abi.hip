@@ -37,12 +37,14 @@ struct Layer {
 struct Pending { int k; hipEvent_t e0, e1; };
 
 void build_worklist(const int32_t* rp, int64_t n_rows, WorkList& w) {
-    w.items.clear(); w.slot_info.clear(); w.n_slots = 0;
+    w.items.clear(); w.slot_info.clear(); w.n_slots = 0; w.n_split = 0;
+    std::vector<int32_t> firsts;
     // pass 1: segments of split rows first (the longest items start earliest)
     for (int64_t r = 0; r < n_rows; ++r) {
         const int32_t b = rp[r], e = rp[r + 1];
         if (e - b <= kSegEdges) continue;
         const int32_t nseg = (e - b + kSegEdges - 1) / kSegEdges, first = w.n_slots;
+        firsts.push_back(first);
         for (int32_t sgm = 0; sgm < nseg; ++sgm) {
             const int32_t sb = b + sgm * kSegEdges, se = std::min(e, sb + kSegEdges);
             const int32_t item = (int32_t)(w.items.size() / 4);
@@ -58,6 +60,8 @@ void build_worklist(const int32_t* rp, int64_t n_rows, WorkList& w) {
         w.items.insert(w.items.end(), {(int32_t)r, b, e, -1});
     }
     w.n_items = (int64_t)(w.items.size() / 4);
+    w.n_split = (int32_t)firsts.size();                 // appended after the per-slot entries: one int4 per split row
+    for (int32_t f : firsts) w.slot_info.insert(w.slot_info.end(), {f, 0, 0, 0});
 }
 
 }  // namespace gat
@@ -208,7 +212,7 @@ static int ensure_buffers(gat_ctx* c) {
     if (!c->cfg.flat_lrelu_index) GAT_TRY(dalloc(c, &c->gH, N * c->layers[L - 1].D));
     // work items (rows / hub-row segments) of the wave-per-item kernels
     GAT_TRY(dalloc(c, &c->items, std::max<int64_t>(c->work.n_items, 1)));
-    GAT_TRY(dalloc(c, &c->slot_info, std::max<int32_t>(c->work.n_slots, 1)));
+    GAT_TRY(dalloc(c, &c->slot_info, std::max<int32_t>(c->work.n_slots + c->work.n_split, 1)));
     GAT_TRY(dalloc(c, &c->part_acc, (int64_t)std::max<int32_t>(c->work.n_slots, 1) * c->HDmax));
     GAT_TRY(dalloc(c, &c->part_mz, (int64_t)std::max<int32_t>(c->work.n_slots, 1) * 2 * c->Hmax));
     if (c->work.n_items > 0)
@@ -573,7 +577,7 @@ int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
     a.alpha = y.alpha; a.hpre = y.hpre; a.hout = y.hout; a.mstat = y.mstat; a.zstat = y.zstat;
     a.n_rows = c->n_rows; a.n_table = c->n_table; a.bf16 = bf16(c); a.H = y.H; a.D = y.D; a.is_last = (l == c->cfg.num_layers - 1);
     a.slope = c->cfg.negative_slope;
-    a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
+    a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots; a.n_split = c->work.n_split;
     a.part_acc = c->part_acc; a.part_mz = c->part_mz;
     Scope t(c, GAT_K_EDGE_FWD);
     return launch_edge_forward(a, c->stream);
@@ -628,7 +632,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.g_raw = l < c->cfg.num_layers - 1;           // hidden layers: written by launch_grad_x without the LReLU' factor
     a.gh = (l == c->cfg.num_layers - 1) ? c->gH : nullptr;
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
-    a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots;
+    a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots; a.n_split = c->work.n_split;
     a.part_acc = c->part_acc;
     a.dbg = c->dbg;
     a.ga_partial = c->ga_partial; a.n_rows = c->n_rows; a.n_table = c->n_table; a.bf16 = bf16(c); a.H = y.H; a.D = y.D;
@@ -1012,7 +1016,7 @@ struct TmpBufs {
         build_worklist(rp.data(), n, w);
         float *fi, *fs;
         GAT_TRY(get(&fi, std::max<int64_t>(w.n_items, 1) * 4));
-        GAT_TRY(get(&fs, std::max<int64_t>(w.n_slots, 1) * 4));
+        GAT_TRY(get(&fs, std::max<int64_t>(w.n_slots + w.n_split, 1) * 4));
         GAT_TRY(get(&part_acc, (int64_t)std::max<int32_t>(w.n_slots, 1) * hd));
         GAT_TRY(get(&part_mz, (int64_t)std::max<int32_t>(w.n_slots, 1) * 2 * h));
         items = (int4*)fi; slot_info = (int4*)fs;
@@ -1039,7 +1043,7 @@ int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, con
     a.mstat = ms; a.zstat = zs;
     a.hpre = d_hpre; a.hout = d_hout; a.n_rows = n; a.n_table = n; a.H = h; a.D = d; a.is_last = is_last; a.slope = slope;
     GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
-    a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots;
+    a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots; a.n_split = t.w.n_split;
     a.part_acc = t.part_acc; a.part_mz = t.part_mz;
     GAT_TRY(launch_edge_forward(a, s));
     GAT_TRY(launch_transpose_eh_to_he(alpha, d_attn_coeff, e, h, s));
@@ -1073,7 +1077,7 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
         fa.row_ptr = d_row_ptr; fa.col_idx = d_col_idx; fa.PL = PL; fa.PR = PR; fa.a = d_a;
         fa.alpha = edge_fast_path(h, d, n) ? nullptr : alpha; fa.hpre = hp_tmp; fa.hout = ho_tmp; fa.mstat = ms; fa.zstat = zs;
         fa.n_rows = n; fa.n_table = n; fa.H = h; fa.D = d; fa.is_last = 0; fa.slope = slope;
-        fa.items = t.items; fa.n_items = t.w.n_items; fa.slot_info = t.slot_info; fa.n_slots = t.w.n_slots;
+        fa.items = t.items; fa.n_items = t.w.n_items; fa.slot_info = t.slot_info; fa.n_slots = t.w.n_slots; fa.n_split = t.w.n_split;
         fa.part_acc = t.part_acc; fa.part_mz = t.part_mz;
         GAT_TRY(launch_edge_forward(fa, s));
     }
@@ -1085,7 +1089,7 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     a.ga_blocks = edge_fast_path(h, d, n) ? edge_backward_blocks(t.w.n_items, h, d, false, false, false)
                                        : edge_backward_blocks(n * 4, h, d, false, false, false);
     a.n_rows = n; a.n_table = n; a.H = h; a.D = d; a.slope = slope;
-    a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots;
+    a.items = t.items; a.n_items = t.w.n_items; a.slot_info = t.slot_info; a.n_slots = t.w.n_slots; a.n_split = t.w.n_split;
     a.part_acc = t.part_acc;
     GAT_TRY(launch_edge_backward(a, s));
     GAT_TRY(launch_reduce_partials_add(gap, a.ga_blocks, HD, d_grad_a, s));

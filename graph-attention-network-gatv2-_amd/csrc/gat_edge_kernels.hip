@@ -341,10 +341,12 @@ __global__ __launch_bounds__(256) void edge_fwd_fix_kernel(EdgeFwdArgs A) {
     constexpr int H = HD / D;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x * 4 + wave;
-    if (slot >= A.n_slots) return;
+    // with alpha every segment normalises its own slice (wave per slot); without it only the row outputs
+    // remain: wave per SPLIT ROW (the first-slot list appended to slot_info)
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= (ALPHA ? A.n_slots : A.n_split)) return;
+    const int slot = ALPHA ? k : A.slot_info[A.n_slots + k].x;
     const int4 info = A.slot_info[slot];             // {row, first_slot, nseg, item}
-    if (!ALPHA && slot != info.y) return;            // without alpha only the row outputs remain
     const int4 item = A.items[info.w];
     const int c = lane % HD;
     float m = -1e9f * kLog2e, Z = 0.f, acc = 0.f;
@@ -482,14 +484,13 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
 
 // gPR of split rows: sum of the row's segment partials in segment order (one thread per channel).
 __global__ __launch_bounds__(256) void edge_bwd_fix_kernel(const int4* __restrict__ slot_info, int32_t n_slots,
-                                                          const float* __restrict__ part, float* __restrict__ gPR,
-                                                          int32_t HD) {
+                                                          int32_t n_split, const float* __restrict__ part,
+                                                          float* __restrict__ gPR, int32_t HD) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t slot = t / HD;
+    const int64_t k = t / HD;                        // k-th split row
     const int c = (int)(t % HD);
-    if (slot >= n_slots) return;
-    const int4 info = slot_info[slot];
-    if (slot != info.y) return;
+    if (k >= n_split) return;
+    const int4 info = slot_info[slot_info[n_slots + k].x];
     float s = 0.f;
     for (int k = info.y; k < info.y + info.z; ++k) s += part[(int64_t)k * HD + c];
     gPR[(int64_t)info.x * HD + c] = s;
@@ -623,7 +624,8 @@ int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
     if (a.items == nullptr) return fail(GAT_E_INVALID, "edge_forward: work-item list missing");
     const int64_t blocks = (a.n_items + 3) / 4;
     if (a.mstat == nullptr || a.zstat == nullptr) return fail(GAT_E_INVALID, "edge_forward: stats buffers missing");
-    const dim3 grid((unsigned)blocks), fgrid((unsigned)((a.n_slots + 3) / 4)), block(256);
+    const dim3 grid((unsigned)blocks), block(256);
+    const dim3 fgrid((unsigned)(((a.alpha != nullptr ? a.n_slots : a.n_split) + 3) / 4));
     if (a.alpha != nullptr) {
         if (a.bf16) hipLaunchKernelGGL((edge_fwd_kernel<HD, D, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((edge_fwd_kernel<HD, D, true, false>), grid, block, 0, s, a);
@@ -686,9 +688,9 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
     }
     GAT_HIP(hipGetLastError());
     if (a.n_slots > 0) {
-        const int64_t threads = (int64_t)a.n_slots * HD;
+        const int64_t threads = (int64_t)a.n_split * HD;
         hipLaunchKernelGGL(edge_bwd_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
-                           a.slot_info, a.n_slots, a.part_acc, a.gPR, HD);
+                           a.slot_info, a.n_slots, a.n_split, a.part_acc, a.gPR, HD);
         GAT_HIP(hipGetLastError());
     }
     return 0;

@@ -52,6 +52,7 @@ struct EdgeFwdArgs {
     int64_t n_items;
     const int4* slot_info;    // [n_slots] {row, first_slot, nseg, item}
     int32_t n_slots;
+    int32_t n_split;          // split rows: slot_info[n_slots + k].x = first slot of the k-th
     float* part_acc;          // [n_slots][HD]  per-segment partial sums of split rows
     float* part_mz;           // [n_slots][2H]  per-segment (max, sum)
 };
@@ -62,9 +63,10 @@ struct EdgeFwdArgs {
 constexpr int kSegEdges = 128;
 struct WorkList {
     std::vector<int32_t> items;       // 4 per item
-    std::vector<int32_t> slot_info;   // 4 per slot
+    std::vector<int32_t> slot_info;   // 4 per slot {row, first slot, segments, item}; then 4 per SPLIT ROW {first slot,-,-,-}
     int64_t n_items = 0;
     int32_t n_slots = 0;
+    int32_t n_split = 0;              // rows cut into segments (entries n_slots .. n_slots+n_split-1 of slot_info)
 };
 void build_worklist(const int32_t* row_ptr, int64_t n_rows, WorkList& w);
 int launch_edge_forward(const EdgeFwdArgs& a, hipStream_t s);
@@ -100,6 +102,7 @@ struct EdgeBwdArgs {
     int64_t n_items;
     const int4* slot_info;
     int32_t n_slots;
+    int32_t n_split;          // split rows: slot_info[n_slots + k].x = first slot of the k-th
     float* part_acc;          // [n_slots][HD]  per-segment gPR partials of split rows
     int32_t dbg;
 };
