@@ -127,6 +127,18 @@ __global__ __launch_bounds__(256) void csc_sum4(const int* __restrict__ ptr, con
         if (r == 0 && s0 + k < n) out[(s0 + k) * 16 + q] = acc;
     }
 }
+// mixed read + write ceiling: y[i] = x[i] (the backward edge kernel reads ~19 GB and writes ~16.5 GB per launch)
+template <int U>
+__global__ __launch_bounds__(256) void stream_copy(const float4* __restrict__ x, float4* __restrict__ y, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * 256 * U;
+    for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i < n4; i += stride) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (i + u * 256 < n4) ? x[i + u * 256] : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (i + u * 256 < n4) y[i + u * 256] = v[u];
+    }
+}
 template <class F> float timeit(F f) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(); CK(hipDeviceSynchronize());
@@ -141,6 +153,15 @@ int main() {
         float m4 = timeit([&] { stream_sum<4><<<blocks, 256>>>(x, n4, out); });
         float m8 = timeit([&] { stream_sum<8><<<blocks, 256>>>(x, n4, out); });
         printf("grid-stride blocks=%5d  U=4 %.2f ms %.2f TB/s | U=8 %.2f ms %.2f TB/s\n", blocks, m4, bytes / m4 / 1e9, m8, bytes / m8 / 1e9);
+    }
+    {
+        float4* y; CK(hipMalloc(&y, bytes));
+        for (int blocks : {2048, 8192}) {
+            float m4 = timeit([&] { stream_copy<4><<<blocks, 256>>>(x, y, n4); });
+            float m8 = timeit([&] { stream_copy<8><<<blocks, 256>>>(x, y, n4); });
+            printf("copy blocks=%5d  U=4 %.2f ms %.2f TB/s (r+w) | U=8 %.2f ms %.2f TB/s\n", blocks, m4, 2.0 * bytes / m4 / 1e9, m8, 2.0 * bytes / m8 / 1e9);
+        }
+        CK(hipFree(y));
     }
     for (int rows : {25, 32, 128}) {
         const size_t n_seg = n4 / 16 / rows;
