@@ -482,6 +482,164 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward edge pass, PACKED lane layout (training path: store mode, no taps): a lane owns TWO adjacent
+// channels, H*D/2 lanes own an edge, so a wave-instruction covers 2x the edges (H*D = 64: two 256-B rows
+// per dwordx2 gather / store) and the per-channel arithmetic runs as packed fp32 (v_pk_add/mul/fma_f32).
+// Per edge that is half the VALU and half the memory instructions of the layout above — the fp32 backward
+// sits between its VALU floor and its HBM floor, the bf16 one is pure instruction issue.  Same math, same
+// per-head summation tree up to the pairing of adjacent channels.
+// ------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int HD, bool BF>
+__device__ __forceinline__ v2f gather_row2(const float* __restrict__ table, int row, int cp) {
+    if constexpr (BF) {
+        const uint32_t off = (uint32_t)row * (uint32_t)(HD * 2) + (uint32_t)cp * 4u;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(table) + off);
+        return v2f{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+    } else {
+        const uint32_t off = (uint32_t)row * (uint32_t)(HD * 4) + (uint32_t)cp * 8u;
+        return *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(table) + off);
+    }
+}
+template <int HD, bool BF>
+__device__ __forceinline__ void store_row2(float* __restrict__ msg, int slot, int cp, v2f v) {
+    if constexpr (BF) {
+        char* rowb = reinterpret_cast<char*>(msg) + (int64_t)slot * (HD * 2);
+        *reinterpret_cast<uint32_t*>(rowb + cp * 4) = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    } else {
+        char* rowb = reinterpret_cast<char*>(msg) + (int64_t)slot * (HD * 4);
+        *reinterpret_cast<v2f*>(rowb + cp * 8) = v;
+    }
+}
+__device__ __forceinline__ v2f lrelu2(v2f s, float slope) {
+    const v2f t = s * slope;
+    return v2f{fmaxf(s.x, t.x), fmaxf(s.y, t.y)};
+}
+
+template <int HD, int D, int UU, int DBG, bool BF>
+__device__ __forceinline__ void bwd2_chunk(const EdgeBwdArgs& A, int e0, int e_end, int e_end_v, int cp, int gidx,
+                                           int srcv, int posv, v2f g, v2f pr, float dot, v2f ac, v2f acs, v2f ac2,
+                                           float m2, float inv, v2f& ga, v2f& gpr) {
+    constexpr int LPE = HD / 2;         // lanes per edge
+    constexpr int G = 64 / LPE;         // edges per wave-instruction
+    constexpr int D2 = D / 2;           // lanes per head
+    v2f v[UU];
+    int sid[UU];
+    // srcv / posv: the chunk's <= 16 edge indices, lane k holding edge e0+k (loaded by the caller one chunk ahead,
+    // with ONE coalesced load each), handed to the owning lanes through the LDS crossbar: per-lane index loads
+    // would put a second memory latency in front of every gather
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        v[u] = gather_row2<HD, BF>(A.PL, __shfl(srcv, u * G + gidx), cp);
+        sid[u] = __shfl(posv, u * G + gidx);
+    }
+    constexpr int P = UU > 8 ? 8 : UU;
+#pragma unroll
+    for (int p0 = 0; p0 < UU; p0 += P) {
+        float al[P], ga_[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const v2f t = ac2 * lrelu2(v[p0 + q] + pr, A.slope);
+            al[q] = t.x + t.y;
+        }
+        group_sum_n<D2, P>(al);
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            al[q] = exp2_fast(al[q] - m2) * inv;
+            const v2f t = g * v[p0 + q];
+            ga_[q] = t.x + t.y;
+        }
+        group_sum_n<D2, P>(ga_);
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const int u = p0 + q;
+            const int j = e0 + u * G + gidx;
+            const bool valid = j < e_end_v;
+            const float ge = valid ? al[q] * (ga_[q] - dot) : 0.f;   // padded slots contribute nothing
+            const v2f s = v[u] + pr;
+            const v2f sel = v2f{s.x > 0.f ? ac.x : acs.x, s.y > 0.f ? ac.y : acs.y};   // a * LReLU'(s)
+            const v2f gs = ge * sel;
+            ga += ge * lrelu2(s, A.slope);
+            gpr += gs;
+            const v2f msg = g * al[q] + gs;                      // d/dPL[src] from this edge
+            if (valid && DBG != 1) store_row2<HD, BF>(A.msg, sid[u], cp, msg);
+        }
+    }
+}
+
+template <int HD, int D, int DBG = 0, bool BF = false>
+__global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) {
+    constexpr int LPE = HD / 2, G = 64 / LPE, D2 = D / 2, H = HD / D;
+    constexpr int U = 16 / G;
+    constexpr int CH = 16;
+    __shared__ float red[4][HD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cp = lane % LPE, gidx = lane / LPE;
+    const int c = 2 * cp;                                        // first of the lane's two channels
+    const v2f ac = *reinterpret_cast<const v2f*>(A.a + c);
+    const v2f acs = ac * A.slope;
+    const v2f ac2 = ac * kLog2e;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    v2f ga = v2f{0.f, 0.f};
+
+    for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < A.n_items; it += nwaves) {
+        const int4 item = A.items[it];
+        const int64_t row = item.x;
+        const int b = item.y, e_end = item.z, slot = item.w;
+        const int e_end_v = per_lane(e_end);
+        const v2f hp = *reinterpret_cast<const v2f*>(A.hpre + row * HD + c);
+        const v2f dsel = v2f{hp.x > 0.f ? 1.0f : A.slope, hp.y > 0.f ? 1.0f : A.slope};
+        v2f g;
+        if (A.gh != nullptr) g = *reinterpret_cast<const v2f*>(A.gh + row * D + (c % D)) * dsel * (1.0f / (float)H);   // E:598-603
+        else {
+            g = *reinterpret_cast<const v2f*>(A.g + row * HD + c);
+            if (A.g_raw) g = g * dsel;                           // E:888-892 applied by the consumer
+        }
+        const v2f pr = *reinterpret_cast<const v2f*>(A.PR + row * HD + c);
+        const v2f gh2 = g * hp;
+        const float dot = group_sum<D2>(gh2.x + gh2.y);
+        const float m2 = A.mstat[row * H + c / D];
+        const float inv = __builtin_amdgcn_rcpf(A.zstat[row * H + c / D] + 1e-8f);
+        v2f gpr = v2f{0.f, 0.f};
+        // edge indices of a chunk: lane k < 16 holds edge e0+k (clamped into the item: no predicate needed)
+        auto load_idx = [&](int e0, int& srcv, int& posv) {
+            const int jl = e0 + (lane & (CH - 1));
+            const int jlc = jl < e_end ? jl : e_end - 1;
+            srcv = A.col_idx[jlc];
+            posv = (DBG == 2) ? jlc : A.pos[jlc];
+        };
+        int srcv, posv;
+        load_idx(b, srcv, posv);
+        for (int e0 = b; e0 < e_end; e0 += CH) {
+            int srcn = 0, posn = 0;
+            if (e0 + CH < e_end) load_idx(e0 + CH, srcn, posn);      // next chunk's indices: in flight during this one
+            if constexpr (U >= 2) {
+                if (e_end - e0 <= CH / 2) bwd2_chunk<HD, D, U / 2, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
+                else bwd2_chunk<HD, D, U, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
+            } else {
+                bwd2_chunk<HD, D, U, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
+            }
+            srcv = srcn; posv = posn;
+        }
+#pragma unroll
+        for (int off = LPE; off < 64; off <<= 1) { gpr.x += __shfl_xor(gpr.x, off); gpr.y += __shfl_xor(gpr.y, off); }
+        if (gidx == 0) {
+            float* dst = slot < 0 ? A.gPR + row * HD + c : A.part_acc + (int64_t)slot * HD + c;   // segment partial -> fix kernel
+            *reinterpret_cast<v2f*>(dst) = gpr;
+        }
+    }
+#pragma unroll
+    for (int off = LPE; off < 64; off <<= 1) { ga.x += __shfl_xor(ga.x, off); ga.y += __shfl_xor(ga.y, off); }
+    if (gidx == 0) { red[wave][c] = ga.x; red[wave][c + 1] = ga.y; }
+    __syncthreads();
+    if (threadIdx.x < HD)
+        A.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // gPR of split rows: sum of the row's segment partials in segment order (one thread per channel).
 __global__ __launch_bounds__(256) void edge_bwd_fix_kernel(const int4* __restrict__ slot_info, int32_t n_slots,
                                                           int32_t n_split, const float* __restrict__ part,
@@ -655,9 +813,17 @@ static int resident_blocks(const void* fn) {
     (void)hipGetLastError();
     return cache[fn] = per_cu * (cus > 0 ? cus : 256);
 }
+// GAT_BWD_PACKED=0 keeps the one-channel-per-lane kernel (A/B)
+static bool packed_backward() {
+    static const bool v = [] { const char* e = getenv("GAT_BWD_PACKED"); return !(e && e[0] == '0'); }();
+    return v;
+}
 struct BwdSel { bool store, taps, bf16; };
 template <int HD, int D, bool BF>
 const void* bwd_variant(bool store, bool taps) {
+    if constexpr (D % 2 == 0) {
+        if (store && !taps && packed_backward()) return (const void*)edge_bwd2_kernel<HD, D, 0, BF>;
+    }
     return store ? (taps ? (const void*)edge_bwd_kernel<HD, D, true, true, 0, BF> : (const void*)edge_bwd_kernel<HD, D, true, false, 0, BF>)
                  : (taps ? (const void*)edge_bwd_kernel<HD, D, false, true, 0, BF> : (const void*)edge_bwd_kernel<HD, D, false, false, 0, BF>);
 }
@@ -675,7 +841,16 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
         if (store && !taps && a.dbg == 1) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 1>), grid, block, 0, s, a); return 0; }
         if (store && !taps && a.dbg == 2) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 2>), grid, block, 0, s, a); return 0; }
     }
-    if (a.bf16) {
+    bool launched = false;
+    if constexpr (D % 2 == 0) {
+        if (store && !taps && packed_backward()) {
+            if (a.bf16) hipLaunchKernelGGL((edge_bwd2_kernel<HD, D, 0, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((edge_bwd2_kernel<HD, D, 0, false>), grid, block, 0, s, a);
+            launched = true;
+        }
+    }
+    if (launched) {
+    } else if (a.bf16) {
         if (store && taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, true, 0, true>), grid, block, 0, s, a);
         else if (store) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 0, true>), grid, block, 0, s, a);
         else if (taps) hipLaunchKernelGGL((edge_bwd_kernel<HD, D, false, true, 0, true>), grid, block, 0, s, a);
