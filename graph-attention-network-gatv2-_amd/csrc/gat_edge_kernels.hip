@@ -518,6 +518,114 @@ __device__ __forceinline__ v2f lrelu2(v2f s, float slope) {
     return v2f{fmaxf(s.x, t.x), fmaxf(s.y, t.y)};
 }
 
+// Forward edge pass in the packed layout (training path: alpha not materialised).  Same online softmax as
+// fwd_chunk; partials of split rows go to the same [slot][HD] / [slot][2H] arrays, so edge_fwd_fix_kernel
+// finishes them unchanged.
+template <int HD, int D, int UU, bool BF>
+__device__ __forceinline__ void fwd2_chunk(const EdgeFwdArgs& A, int e0, int e_end_v, int cp, int gidx, int srcv,
+                                           v2f pr, v2f ac2, float& m, float& Z, v2f& acc) {
+    constexpr int LPE = HD / 2, G = 64 / LPE, D2 = D / 2;
+    v2f v[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) v[u] = gather_row2<HD, BF>(A.PL, __shfl(srcv, u * G + gidx), cp);
+    float t[UU];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const v2f x = ac2 * lrelu2(v[u] + pr, A.slope);
+        t[u] = x.x + x.y;
+    }
+    group_sum_n<D2, UU>(t);
+    float cm = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const int j = e0 + u * G + gidx;
+        t[u] = (j < e_end_v) ? t[u] : -INFINITY;
+        cm = fmaxf(cm, t[u]);
+    }
+    const float mn = fmaxf(m, cm);
+    const float scale = exp2_fast(m - mn);
+    Z *= scale;
+    acc = acc * scale;
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+        const float p = exp2_fast(t[u] - mn);        // 0 for padded slots
+        Z += p;
+        acc += p * v[u];
+    }
+    m = mn;
+}
+
+template <int HD, int D, bool BF = false>
+__global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
+    constexpr int LPE = HD / 2, G = 64 / LPE, D2 = D / 2, H = HD / D;
+    constexpr int CH = 16;
+    constexpr int U = CH / G;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t it = (int64_t)blockIdx.x * 4 + wave;
+    if (it >= A.n_items) return;
+    const int4 item = A.items[it];
+    const int64_t row = item.x;
+    const int b = item.y, e_end = item.z, slot = item.w;
+    const int e_end_v = per_lane(e_end);
+    const int cp = lane % LPE, gidx = lane / LPE;
+    const int c = 2 * cp;
+    const v2f pr = *reinterpret_cast<const v2f*>(A.PR + row * HD + c);
+    const v2f ac2 = *reinterpret_cast<const v2f*>(A.a + c) * kLog2e;
+    float m = -1e9f * kLog2e, Z = 0.f;               // E:336 seeds the max with -1e9f
+    v2f acc = v2f{0.f, 0.f};
+    auto load_idx = [&](int e0) {
+        const int jl = e0 + (lane & (CH - 1));
+        return A.col_idx[jl < e_end ? jl : e_end - 1];
+    };
+    int srcv = load_idx(b);
+    for (int e0 = b; e0 < e_end; e0 += CH) {
+        const int srcn = (e0 + CH < e_end) ? load_idx(e0 + CH) : 0;
+        if constexpr (U >= 2) {
+            if (e_end - e0 <= CH / 2) fwd2_chunk<HD, D, U / 2, BF>(A, e0, e_end_v, cp, gidx, srcv, pr, ac2, m, Z, acc);
+            else fwd2_chunk<HD, D, U, BF>(A, e0, e_end_v, cp, gidx, srcv, pr, ac2, m, Z, acc);
+        } else {
+            fwd2_chunk<HD, D, U, BF>(A, e0, e_end_v, cp, gidx, srcv, pr, ac2, m, Z, acc);
+        }
+        srcv = srcn;
+    }
+    // merge the G edge groups (online-softmax combine); afterwards all groups agree
+#pragma unroll
+    for (int off = LPE; off < 64; off <<= 1) {
+        const float mo = __shfl_xor(m, off), Zo = __shfl_xor(Z, off);
+        const v2f ao = v2f{__shfl_xor(acc.x, off), __shfl_xor(acc.y, off)};
+        const float mn = fmaxf(m, mo);
+        const float s1 = exp2_fast(m - mn), s2 = exp2_fast(mo - mn);
+        Z = Z * s1 + Zo * s2;
+        acc = acc * s1 + ao * s2;
+        m = mn;
+    }
+    if (slot >= 0) {                                 // one segment of a long row: partial (m, Z, acc)
+        if (gidx == 0) {
+            *reinterpret_cast<v2f*>(A.part_acc + (int64_t)slot * HD + c) = acc;
+            if ((c % D) == 0) {
+                A.part_mz[(int64_t)slot * 2 * H + c / D] = m;
+                A.part_mz[(int64_t)slot * 2 * H + H + c / D] = Z;
+            }
+        }
+        return;
+    }
+    const v2f hp = acc * __builtin_amdgcn_rcpf(Z + 1e-8f);       // E:379 epsilon
+    if (gidx == 0) {
+        *reinterpret_cast<v2f*>(A.hpre + row * HD + c) = hp;
+        if ((c % D) == 0) { A.mstat[row * H + c / D] = m; A.zstat[row * H + c / D] = Z; }
+    }
+    const v2f act = lrelu2(hp, A.slope);
+    if (!A.is_last) {
+        if (gidx == 0) *reinterpret_cast<v2f*>(A.hout + row * HD + c) = act;      // concat heads (E:452-457)
+    } else {
+        v2f t = act;                                 // activate, then average heads (E:440-449)
+#pragma unroll
+        for (int off = D2; off < LPE; off <<= 1) { t.x += __shfl_xor(t.x, off); t.y += __shfl_xor(t.y, off); }
+        if (lane < D2) *reinterpret_cast<v2f*>(A.hout + row * D + c) = t / (float)H;
+    }
+}
+
 template <int HD, int D, int UU, int DBG, bool BF>
 __device__ __forceinline__ void bwd2_chunk(const EdgeBwdArgs& A, int e0, int e_end, int e_end_v, int cp, int gidx,
                                            int srcv, int posv, v2f g, v2f pr, float dot, v2f ac, v2f acs, v2f ac2,
@@ -777,6 +885,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// GAT_PACKED=0 keeps the one-channel-per-lane kernels on the training path too (A/B)
+static bool packed_layout() {
+    static const bool v = [] { const char* e = getenv("GAT_PACKED"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 template <int HD, int D>
 int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
     if (a.items == nullptr) return fail(GAT_E_INVALID, "edge_forward: work-item list missing");
@@ -789,8 +903,18 @@ int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((edge_fwd_kernel<HD, D, true, false>), grid, block, 0, s, a);
         if (a.n_slots > 0) hipLaunchKernelGGL((edge_fwd_fix_kernel<HD, D, true>), fgrid, block, 0, s, a);
     } else {
-        if (a.bf16) hipLaunchKernelGGL((edge_fwd_kernel<HD, D, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((edge_fwd_kernel<HD, D, false, false>), grid, block, 0, s, a);
+        bool launched = false;
+        if constexpr (D % 2 == 0) {
+            if (packed_layout()) {                   // two channels per lane (see edge_fwd2_kernel)
+                if (a.bf16) hipLaunchKernelGGL((edge_fwd2_kernel<HD, D, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((edge_fwd2_kernel<HD, D, false>), grid, block, 0, s, a);
+                launched = true;
+            }
+        }
+        if (!launched) {
+            if (a.bf16) hipLaunchKernelGGL((edge_fwd_kernel<HD, D, false, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((edge_fwd_kernel<HD, D, false, false>), grid, block, 0, s, a);
+        }
         if (a.n_slots > 0) hipLaunchKernelGGL((edge_fwd_fix_kernel<HD, D, false>), fgrid, block, 0, s, a);
     }
     GAT_HIP(hipGetLastError());
@@ -813,11 +937,7 @@ static int resident_blocks(const void* fn) {
     (void)hipGetLastError();
     return cache[fn] = per_cu * (cus > 0 ? cus : 256);
 }
-// GAT_BWD_PACKED=0 keeps the one-channel-per-lane kernel (A/B)
-static bool packed_backward() {
-    static const bool v = [] { const char* e = getenv("GAT_BWD_PACKED"); return !(e && e[0] == '0'); }();
-    return v;
-}
+static bool packed_backward() { return packed_layout(); }
 struct BwdSel { bool store, taps, bf16; };
 template <int HD, int D, bool BF>
 const void* bwd_variant(bool store, bool taps) {
