@@ -506,10 +506,10 @@ __device__ __forceinline__ v2f gather_row2(const float* __restrict__ table, int 
 template <int HD, bool BF>
 __device__ __forceinline__ void store_row2(float* __restrict__ msg, int slot, int cp, v2f v) {
     if constexpr (BF) {
-        char* rowb = reinterpret_cast<char*>(msg) + (int64_t)slot * (HD * 2);
+        char* rowb = reinterpret_cast<char*>(msg) + (uint64_t)(uint32_t)slot * (HD * 2);   // slots are >= 0: zero-extend, no 64-bit shift pair
         *reinterpret_cast<uint32_t*>(rowb + cp * 4) = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
     } else {
-        char* rowb = reinterpret_cast<char*>(msg) + (int64_t)slot * (HD * 4);
+        char* rowb = reinterpret_cast<char*>(msg) + (uint64_t)(uint32_t)slot * (HD * 4);
         *reinterpret_cast<v2f*>(rowb + cp * 8) = v;
     }
 }
