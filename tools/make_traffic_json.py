@@ -27,7 +27,7 @@ def load(d):
         if cls is None:
             continue
         agg[cls][r["Counter_Name"]] += float(r["Counter_Value"])
-        if "fix" not in r["Kernel_Name"]:
+        if "fix" not in r["Kernel_Name"] and "chunk" not in r["Kernel_Name"]:      # helpers ride with their main kernel
             disp[cls].add(r["Dispatch_Id"])
     return agg, disp
 
