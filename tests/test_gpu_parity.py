@@ -243,7 +243,7 @@ def test_source_hub_both_gpl_sum_variants(pkg, orc, group, monkeypatch):
         from conftest import grad_close
         pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
         rng = np.random.default_rng(17)
-        n = 640          # source 3 is in every row: 640 slots = 3 chunks of the heavy-source path (kHeavySlots = 256)
+        n = 1100         # source 3 is in every row: 1100 slots = 3 chunks of the heavy-source path (kHeavySlots = 512)
         rows = [np.unique(np.concatenate([[3] if i % 4 else [3, 7], rng.integers(0, n, rng.integers(0, 6))])) for i in range(n)]
         rp = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
         ci = np.concatenate(rows).astype(np.int32)
