@@ -37,6 +37,8 @@ struct Layer {
 struct Pending { int k; hipEvent_t e0, e1; };
 
 void build_worklist(const int32_t* rp, int64_t n_rows, WorkList& w) {
+    static const int seg_env = [] { const char* e = getenv("GAT_SEG_EDGES"); const int v = e ? atoi(e) : 0; return v >= 16 ? v : 0; }();
+    const int kSegEdges = seg_env ? seg_env : gat::kSegEdges;       // GAT_SEG_EDGES=<n>: sweep of the hub-row segment length
     w.items.clear(); w.slot_info.clear(); w.n_slots = 0; w.n_split = 0;
     std::vector<int32_t> firsts;
     // pass 1: segments of split rows first (the longest items start earliest)

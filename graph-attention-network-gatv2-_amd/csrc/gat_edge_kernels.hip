@@ -8,7 +8,7 @@
 //   a1 CSR->COO E:67-84
 // with ONE destination-segmented pass per direction over projected features
 //   PL = X·W_left^T, PR = X·W_right^T   (s[e,h,k] = PL[src,h,k] + PR[dst,h,k]).
-// A wave owns a work item = a CSR row, or a <=128-edge segment of a long row (power-law hubs
+// A wave owns a work item = a CSR row, or a <=256-edge segment of a long row (power-law hubs
 // are split so that no wave runs longer than ~8 chunks).  Every neighbour row PL[src] is one
 // coalesced H*D-float read, the per-head reductions are DPP/shuffle all-reduces, the softmax is
 // online (single gather of PL[src] per edge), h_pre is written once without atomics, and the
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void edge_fwd_fix_kernel(EdgeFwdArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward edge pass, fast path.  Fixed grid, work items dealt round-robin (all items are <= 128
+// Backward edge pass, fast path.  Fixed grid, work items dealt round-robin (all items are <= kSegEdges
 // edges, so the static deal is balanced) — fixed so that the per-block grad_a partials stay small.
 // Per edge: one PL[src] gather, one alpha read, one message row out.
 //   galpha = <g[dst,h,:], PL[src,h,:]>                 (E:632-646)

@@ -60,7 +60,7 @@ struct EdgeFwdArgs {
 // Work decomposition of a CSR graph for the wave-per-item kernels: every row with <= kSegEdges
 // in-edges is one item, longer rows (power-law hubs) are cut into segments of kSegEdges edges
 // (slot >= 0) that are listed first; slot_info describes the split rows for the fix-up kernels.
-constexpr int kSegEdges = 128;
+constexpr int kSegEdges = 256;      // swept 64..512 on the Products shape (GAT_SEG_EDGES): 256 best by ~0.5 %
 struct WorkList {
     std::vector<int32_t> items;       // 4 per item
     std::vector<int32_t> slot_info;   // 4 per slot {row, first slot, segments, item}; then 4 per SPLIT ROW {first slot,-,-,-}

@@ -144,7 +144,7 @@ def test_op_level_entry_points(pkg, orc):
     import torch
     A = pkg.abi
     lib = A.load_library()
-    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 21, 130, 1111, (8, 1), (8, 8), 40, 3, hub=(4, 200))
+    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 21, 130, 1111, (8, 1), (8, 8), 40, 3, hub=(4, 300))
     ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
     dev = torch.device("cuda:0")
     t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _problem(seed=3, n=90, e=700, f=12, c=4, heads=(8, 8), outdims=(8, 8)):
     rng = np.random.default_rng(seed)
-    rp, ci = small_graph(rng, n, e, hub=(5, 150), empty=(0, 44))
+    rp, ci = small_graph(rng, n, e, hub=(5, 300), empty=(0, 44))
     x = rng.standard_normal((n, f)).astype(np.float32)
     lab = rng.integers(0, c, n).astype(np.int32)
     lab[0] = c - 1
