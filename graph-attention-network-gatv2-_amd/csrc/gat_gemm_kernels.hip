@@ -251,13 +251,15 @@ int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, 
 // channels); WM=1 -> 64 x 128 as 1x4 waves of 64x32 (one half, HD = 64 channels: no MFMA spent on
 // padding rows).  Node tiles of 32 staged through two LDS buffers in memory layout ([node][c] and
 // [node][f] are already k-major); global loads of tile t+1 are in flight while tile t is multiplied.
-template <bool VEC4, int WM>
+template <bool VEC4, int WM, int BN = 128>
 __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gPL, const float* __restrict__ gPR,
                                                     const float* __restrict__ X, float* __restrict__ slabs,
                                                     int64_t n_rows, int32_t HD, int32_t F, int64_t kchunk,
                                                     int32_t c_base, int32_t M) {
-    constexpr int KT = 32, BM = 64 * WM, BN = 128;
+    // BN = 64 when F <= 64 (hidden layers: F = H*D of the layer below): no MFMA spent on columns beyond F
+    constexpr int KT = 32, BM = 64 * WM;
     constexpr int WN = 4 / WM, NY = BN / WN / 32;     // waves along f; 32-col MFMA tiles per wave
+    static_assert(NY >= 1, "tile shape");
     __shared__ float As[2][KT][BM];
     __shared__ float Bs[2][KT][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,14 +290,14 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
                 if constexpr (VEC4) {
                     if (c < BM && i0 + c < M) ra[p] = ci < HD ? *reinterpret_cast<const float4*>(gPL + node * HD + ci)
                                                     : *reinterpret_cast<const float4*>(gPR + node * HD + (ci - HD));
-                    if (cj < F) rb[p] = *reinterpret_cast<const float4*>(X + node * F + cj);
+                    if (c < BN && cj < F) rb[p] = *reinterpret_cast<const float4*>(X + node * F + cj);
                 } else {
                     float t[4], u[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int cc = ci + q, jj = cj + q;
                         t[q] = (c < BM && (cc - c_base) < M) ? (cc < HD ? gPL[node * HD + cc] : gPR[node * HD + (cc - HD)]) : 0.f;
-                        u[q] = jj < F ? X[node * F + jj] : 0.f;
+                        u[q] = (c < BN && jj < F) ? X[node * F + jj] : 0.f;
                     }
                     ra[p] = make_float4(t[0], t[1], t[2], t[3]);
                     rb[p] = make_float4(u[0], u[1], u[2], u[3]);
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
             const int idx = tid + 256 * p;
             const int kk = idx >> 5, c = (idx & 31) * 4;
             if (c < BM) *reinterpret_cast<float4*>(&As[buf][kk][c]) = ra[p];
-            *reinterpret_cast<float4*>(&Bs[buf][kk][c]) = rb[p];
+            if (c < BN) *reinterpret_cast<float4*>(&Bs[buf][kk][c]) = rb[p];
         }
     };
 
@@ -352,12 +354,14 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
 }
 
 inline int grad_w_bm(int32_t M) { return (M % 128 == 0 || M % 128 > 64) ? 128 : 64; }
+inline int grad_w_bn(int32_t M, int32_t F) { return (grad_w_bm(M) == 128 && F <= 64) ? 64 : 128; }   // 64 only in the 2x2-wave shape
 
 int64_t grad_w_kchunk(int64_t n_rows, int32_t F, int32_t M) {
-    const int bm = grad_w_bm(M);
-    const int64_t tiles = (((int64_t)M + bm - 1) / bm) * (((int64_t)F + 127) / 128);
+    const int bm = grad_w_bm(M), bn = grad_w_bn(M, F);
+    const int64_t tiles = (((int64_t)M + bm - 1) / bm) * (((int64_t)F + bn - 1) / bn);
     // split-K over exactly the blocks that fit at once (LDS-limited: 64 / 48 KiB per block)
-    int64_t splits = resident_blocks(bm == 128 ? (const void*)gradw_kernel<true, 2> : (const void*)gradw_kernel<true, 1>, 0) / tiles;
+    int64_t splits = resident_blocks(bm == 128 ? (bn == 64 ? (const void*)gradw_kernel<true, 2, 64> : (const void*)gradw_kernel<true, 2>)
+                                               : (const void*)gradw_kernel<true, 1>, 0) / tiles;
     if (splits < 1) splits = 1;
     int64_t kchunk = (n_rows + splits - 1) / splits;
     kchunk = ((kchunk + 31) / 32) * 32;
@@ -409,12 +413,12 @@ int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float
     if (part == kPartRight) gPL_rows = gPR;
     const int64_t kchunk = grad_w_kchunk(n_rows, F, M);
     const int64_t ksplit = (n_rows + kchunk - 1) / kchunk;
-    const int bm = grad_w_bm(M);
-    const dim3 grid((unsigned)((F + 127) / 128), (unsigned)((M + bm - 1) / bm), (unsigned)ksplit);
+    const int bm = grad_w_bm(M), bn = grad_w_bn(M, F);
+    const dim3 grid((unsigned)((F + bn - 1) / bn), (unsigned)((M + bm - 1) / bm), (unsigned)ksplit);
     const bool vec4 = (F % 4 == 0) && (HD % 4 == 0) && aligned16(X) && aligned16(gPL_rows) && aligned16(gPR);
-#define GAT_GRADW(V_, WM_) hipLaunchKernelGGL((gradw_kernel<V_, WM_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M)
-    if (vec4) { if (bm == 128) GAT_GRADW(true, 2); else GAT_GRADW(true, 1); }
-    else { if (bm == 128) GAT_GRADW(false, 2); else GAT_GRADW(false, 1); }
+#define GAT_GRADW(V_, WM_, BN_) hipLaunchKernelGGL((gradw_kernel<V_, WM_, BN_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M)
+    if (vec4) { if (bm == 128 && bn == 64) GAT_GRADW(true, 2, 64); else if (bm == 128) GAT_GRADW(true, 2, 128); else GAT_GRADW(true, 1, 128); }
+    else { if (bm == 128 && bn == 64) GAT_GRADW(false, 2, 64); else if (bm == 128) GAT_GRADW(false, 2, 128); else GAT_GRADW(false, 1, 128); }
 #undef GAT_GRADW
     GAT_HIP(hipGetLastError());
     return launch_reduce_gradw(scratch, (int32_t)ksplit, HD, F, c_base, M, gradW, s);
