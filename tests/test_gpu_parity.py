@@ -299,3 +299,33 @@ def test_step_graph_refused_with_timing(pkg):
     with pytest.raises(pkg.abi.GatError, match="collect_timing"):
         ctx.step_graph(True)
     ctx.close()
+
+
+@pytest.mark.parametrize("hd,d", [(64, 8), (64, 4), (64, 16), (64, 32), (64, 64), (32, 8), (32, 4), (32, 16), (32, 32),
+                                  (16, 4), (16, 8), (16, 16), (8, 4), (8, 8)])
+def test_every_fast_path_shape(pkg, orc, hd, d):
+    """All (H*D, D) instantiations of the wave-per-item kernels — packed training path (no taps) and the
+    one-channel-per-lane tap path — against the oracle: loss, alpha, parameter gradients."""
+    A = pkg.abi
+    h = hd // d
+    cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 100 + hd + d, 120, 1000, (h, h), (d, d), 10, 4, hub=(6, 300), empty=(2,))
+    ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    for keep_taps in (False, True):
+        ctx = pkg.GatContext(cfg.heads, cfg.outdims, cfg.in_dim0, cfg.num_classes, keep_taps=keep_taps)
+        try:
+            ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
+            ctx.params_set(A.PARAM_W, W); ctx.params_set(A.PARAM_A, a); ctx.params_set(A.PARAM_WO, Wo)
+            ctx.zero_grad()
+            loss, correct = ctx.forward()
+            ctx.backward()
+            assert abs(loss - ref.loss_sum_f64) / 120 < TOL and correct == ref.n_correct
+            for l in range(2):
+                assert _relerr(ctx.tap(A.TAP_HPRE, l), ref.taps["hpre"][l]) < TOL
+                if keep_taps:
+                    assert np.abs(ctx.tap(A.TAP_ALPHA, l) - ref.taps["alpha"][l]).max() < TOL
+            got = np.concatenate([ctx.grads_get(g) for g in (A.PARAM_W, A.PARAM_A, A.PARAM_WO)])
+            ok, info = grad_close(got, want, 1e-3)
+            assert ok, (keep_taps, info)
+        finally:
+            ctx.close()
