@@ -490,51 +490,91 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
 // sits between its VALU floor and its HBM floor, the bf16 one is pure instruction issue.  Same math, same
 // per-head summation tree up to the pairing of adjacent channels.
 // ------------------------------------------------------------------------------------------------
-typedef float v2f __attribute__((ext_vector_type(2)));
+// N adjacent channels per lane (N = 2 or 4): ext-vector arithmetic lowers to v_pk_add/mul/fma_f32 pairs
+template <int N> struct VecOf;
+template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<4> { typedef float T __attribute__((ext_vector_type(4))); };
+template <int N> using vnf = typename VecOf<N>::T;
 
-template <int HD, bool BF>
-__device__ __forceinline__ v2f gather_row2(const float* __restrict__ table, int row, int cp) {
+template <int N> __device__ __forceinline__ vnf<N> vzero() {
+    vnf<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = 0.f;
+    return r;
+}
+template <int N> __device__ __forceinline__ float hsum(vnf<N> v) {
+    if constexpr (N == 2) return v[0] + v[1];
+    else return (v[0] + v[1]) + (v[2] + v[3]);
+}
+template <int N> __device__ __forceinline__ vnf<N> lrelu_n(vnf<N> s, float slope) {
+    const vnf<N> t = s * slope;
+    vnf<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fmaxf(s[i], t[i]);
+    return r;
+}
+// s > 0 ? a : b, elementwise
+template <int N> __device__ __forceinline__ vnf<N> select_pos(vnf<N> s, vnf<N> a, vnf<N> b) {
+    vnf<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = s[i] > 0.f ? a[i] : b[i];
+    return r;
+}
+template <int N> __device__ __forceinline__ vnf<N> shfl_xor_n(vnf<N> v, int off) {
+    vnf<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __shfl_xor(v[i], off);
+    return r;
+}
+
+// cp = index of the lane's channel group inside the row (channels cp*N .. cp*N+N-1)
+template <int HD, int N, bool BF>
+__device__ __forceinline__ vnf<N> gather_row_n(const float* __restrict__ table, int row, int cp) {
     if constexpr (BF) {
-        const uint32_t off = (uint32_t)row * (uint32_t)(HD * 2) + (uint32_t)cp * 4u;
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(table) + off);
-        return v2f{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xFFFF0000u)};
+        const uint32_t off = (uint32_t)row * (uint32_t)(HD * 2) + (uint32_t)cp * (uint32_t)(N * 2);
+        const char* p = reinterpret_cast<const char*>(table) + off;
+        vnf<N> r;
+        if constexpr (N == 2) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+            r[0] = __builtin_bit_cast(float, w << 16); r[1] = __builtin_bit_cast(float, w & 0xFFFF0000u);
+        } else {
+            const uint2 w = *reinterpret_cast<const uint2*>(p);
+            r[0] = __builtin_bit_cast(float, w.x << 16); r[1] = __builtin_bit_cast(float, w.x & 0xFFFF0000u);
+            r[2] = __builtin_bit_cast(float, w.y << 16); r[3] = __builtin_bit_cast(float, w.y & 0xFFFF0000u);
+        }
+        return r;
     } else {
-        const uint32_t off = (uint32_t)row * (uint32_t)(HD * 4) + (uint32_t)cp * 8u;
-        return *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(table) + off);
+        const uint32_t off = (uint32_t)row * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4);
+        return *reinterpret_cast<const vnf<N>*>(reinterpret_cast<const char*>(table) + off);
     }
 }
-template <int HD, bool BF>
-__device__ __forceinline__ void store_row2(float* __restrict__ msg, int slot, int cp, v2f v) {
+template <int HD, int N, bool BF>
+__device__ __forceinline__ void store_row_n(float* __restrict__ msg, int slot, int cp, vnf<N> v) {
     if constexpr (BF) {
-        char* rowb = reinterpret_cast<char*>(msg) + (uint64_t)(uint32_t)slot * (HD * 2);   // slots are >= 0: zero-extend, no 64-bit shift pair
-        *reinterpret_cast<uint32_t*>(rowb + cp * 4) = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+        char* p = reinterpret_cast<char*>(msg) + (uint64_t)(uint32_t)slot * (HD * 2) + cp * (N * 2);   // slots are >= 0: zero-extend
+        const uint32_t w0 = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        if constexpr (N == 2) *reinterpret_cast<uint32_t*>(p) = w0;
+        else *reinterpret_cast<uint2*>(p) = make_uint2(w0, (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16));
     } else {
-        char* rowb = reinterpret_cast<char*>(msg) + (uint64_t)(uint32_t)slot * (HD * 4);
-        *reinterpret_cast<v2f*>(rowb + cp * 8) = v;
+        char* p = reinterpret_cast<char*>(msg) + (uint64_t)(uint32_t)slot * (HD * 4) + cp * (N * 4);
+        *reinterpret_cast<vnf<N>*>(p) = v;
     }
-}
-__device__ __forceinline__ v2f lrelu2(v2f s, float slope) {
-    const v2f t = s * slope;
-    return v2f{fmaxf(s.x, t.x), fmaxf(s.y, t.y)};
 }
 
 // Forward edge pass in the packed layout (training path: alpha not materialised).  Same online softmax as
 // fwd_chunk; partials of split rows go to the same [slot][HD] / [slot][2H] arrays, so edge_fwd_fix_kernel
 // finishes them unchanged.
-template <int HD, int D, int UU, bool BF>
+template <int HD, int D, int N, int UU, bool BF>
 __device__ __forceinline__ void fwd2_chunk(const EdgeFwdArgs& A, int e0, int e_end_v, int cp, int gidx, int srcv,
-                                           v2f pr, v2f ac2, float& m, float& Z, v2f& acc) {
-    constexpr int LPE = HD / 2, G = 64 / LPE, D2 = D / 2;
-    v2f v[UU];
+                                           vnf<N> pr, vnf<N> ac2, float& m, float& Z, vnf<N>& acc) {
+    constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N;
+    vnf<N> v[UU];
 #pragma unroll
-    for (int u = 0; u < UU; ++u) v[u] = gather_row2<HD, BF>(A.PL, __shfl(srcv, u * G + gidx), cp);
+    for (int u = 0; u < UU; ++u) v[u] = gather_row_n<HD, N, BF>(A.PL, __shfl(srcv, u * G + gidx), cp);
     float t[UU];
 #pragma unroll
-    for (int u = 0; u < UU; ++u) {
-        const v2f x = ac2 * lrelu2(v[u] + pr, A.slope);
-        t[u] = x.x + x.y;
-    }
-    group_sum_n<D2, UU>(t);
+    for (int u = 0; u < UU; ++u) t[u] = hsum<N>(ac2 * lrelu_n<N>(v[u] + pr, A.slope));
+    group_sum_n<DL, UU>(t);
     float cm = -INFINITY;
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
@@ -555,11 +595,12 @@ __device__ __forceinline__ void fwd2_chunk(const EdgeFwdArgs& A, int e0, int e_e
     m = mn;
 }
 
-template <int HD, int D, bool BF = false>
+template <int HD, int D, int N, bool BF = false>
 __global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
-    constexpr int LPE = HD / 2, G = 64 / LPE, D2 = D / 2, H = HD / D;
+    constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
     constexpr int CH = 16;
     constexpr int U = CH / G;
+    static_assert(D % N == 0 && U >= 1, "lane layout");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t it = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -569,11 +610,11 @@ __global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
     const int b = item.y, e_end = item.z, slot = item.w;
     const int e_end_v = per_lane(e_end);
     const int cp = lane % LPE, gidx = lane / LPE;
-    const int c = 2 * cp;
-    const v2f pr = *reinterpret_cast<const v2f*>(A.PR + row * HD + c);
-    const v2f ac2 = *reinterpret_cast<const v2f*>(A.a + c) * kLog2e;
+    const int c = N * cp;                            // first of the lane's channels
+    const vnf<N> pr = *reinterpret_cast<const vnf<N>*>(A.PR + row * HD + c);
+    const vnf<N> ac2 = *reinterpret_cast<const vnf<N>*>(A.a + c) * kLog2e;
     float m = -1e9f * kLog2e, Z = 0.f;               // E:336 seeds the max with -1e9f
-    v2f acc = v2f{0.f, 0.f};
+    vnf<N> acc = vzero<N>();
     auto load_idx = [&](int e0) {
         const int jl = e0 + (lane & (CH - 1));
         return A.col_idx[jl < e_end ? jl : e_end - 1];
@@ -582,10 +623,10 @@ __global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
     for (int e0 = b; e0 < e_end; e0 += CH) {
         const int srcn = (e0 + CH < e_end) ? load_idx(e0 + CH) : 0;
         if constexpr (U >= 2) {
-            if (e_end - e0 <= CH / 2) fwd2_chunk<HD, D, U / 2, BF>(A, e0, e_end_v, cp, gidx, srcv, pr, ac2, m, Z, acc);
-            else fwd2_chunk<HD, D, U, BF>(A, e0, e_end_v, cp, gidx, srcv, pr, ac2, m, Z, acc);
+            if (e_end - e0 <= CH / 2) fwd2_chunk<HD, D, N, U / 2, BF>(A, e0, e_end_v, cp, gidx, srcv, pr, ac2, m, Z, acc);
+            else fwd2_chunk<HD, D, N, U, BF>(A, e0, e_end_v, cp, gidx, srcv, pr, ac2, m, Z, acc);
         } else {
-            fwd2_chunk<HD, D, U, BF>(A, e0, e_end_v, cp, gidx, srcv, pr, ac2, m, Z, acc);
+            fwd2_chunk<HD, D, N, U, BF>(A, e0, e_end_v, cp, gidx, srcv, pr, ac2, m, Z, acc);
         }
         srcv = srcn;
     }
@@ -593,7 +634,7 @@ __global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
 #pragma unroll
     for (int off = LPE; off < 64; off <<= 1) {
         const float mo = __shfl_xor(m, off), Zo = __shfl_xor(Z, off);
-        const v2f ao = v2f{__shfl_xor(acc.x, off), __shfl_xor(acc.y, off)};
+        const vnf<N> ao = shfl_xor_n<N>(acc, off);
         const float mn = fmaxf(m, mo);
         const float s1 = exp2_fast(m - mn), s2 = exp2_fast(mo - mn);
         Z = Z * s1 + Zo * s2;
@@ -602,7 +643,7 @@ __global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
     }
     if (slot >= 0) {                                 // one segment of a long row: partial (m, Z, acc)
         if (gidx == 0) {
-            *reinterpret_cast<v2f*>(A.part_acc + (int64_t)slot * HD + c) = acc;
+            *reinterpret_cast<vnf<N>*>(A.part_acc + (int64_t)slot * HD + c) = acc;
             if ((c % D) == 0) {
                 A.part_mz[(int64_t)slot * 2 * H + c / D] = m;
                 A.part_mz[(int64_t)slot * 2 * H + H + c / D] = Z;
@@ -610,37 +651,37 @@ __global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
         }
         return;
     }
-    const v2f hp = acc * __builtin_amdgcn_rcpf(Z + 1e-8f);       // E:379 epsilon
+    const vnf<N> hp = acc * __builtin_amdgcn_rcpf(Z + 1e-8f);    // E:379 epsilon
     if (gidx == 0) {
-        *reinterpret_cast<v2f*>(A.hpre + row * HD + c) = hp;
+        *reinterpret_cast<vnf<N>*>(A.hpre + row * HD + c) = hp;
         if ((c % D) == 0) { A.mstat[row * H + c / D] = m; A.zstat[row * H + c / D] = Z; }
     }
-    const v2f act = lrelu2(hp, A.slope);
+    const vnf<N> act = lrelu_n<N>(hp, A.slope);
     if (!A.is_last) {
-        if (gidx == 0) *reinterpret_cast<v2f*>(A.hout + row * HD + c) = act;      // concat heads (E:452-457)
+        if (gidx == 0) *reinterpret_cast<vnf<N>*>(A.hout + row * HD + c) = act;   // concat heads (E:452-457)
     } else {
-        v2f t = act;                                 // activate, then average heads (E:440-449)
+        vnf<N> t = act;                              // activate, then average heads (E:440-449)
 #pragma unroll
-        for (int off = D2; off < LPE; off <<= 1) { t.x += __shfl_xor(t.x, off); t.y += __shfl_xor(t.y, off); }
-        if (lane < D2) *reinterpret_cast<v2f*>(A.hout + row * D + c) = t / (float)H;
+        for (int off = DL; off < LPE; off <<= 1) t += shfl_xor_n<N>(t, off);
+        if (lane < DL) *reinterpret_cast<vnf<N>*>(A.hout + row * D + c) = t / (float)H;
     }
 }
 
-template <int HD, int D, int UU, int DBG, bool BF>
+template <int HD, int D, int N, int UU, int DBG, bool BF>
 __device__ __forceinline__ void bwd2_chunk(const EdgeBwdArgs& A, int e0, int e_end, int e_end_v, int cp, int gidx,
-                                           int srcv, int posv, v2f g, v2f pr, float dot, v2f ac, v2f acs, v2f ac2,
-                                           float m2, float inv, v2f& ga, v2f& gpr) {
-    constexpr int LPE = HD / 2;         // lanes per edge
+                                           int srcv, int posv, vnf<N> g, vnf<N> pr, float dot, vnf<N> ac, vnf<N> acs,
+                                           vnf<N> ac2, float m2, float inv, vnf<N>& ga, vnf<N>& gpr) {
+    constexpr int LPE = HD / N;         // lanes per edge
     constexpr int G = 64 / LPE;         // edges per wave-instruction
-    constexpr int D2 = D / 2;           // lanes per head
-    v2f v[UU];
+    constexpr int DL = D / N;           // lanes per head
+    vnf<N> v[UU];
     int sid[UU];
     // srcv / posv: the chunk's <= 16 edge indices, lane k holding edge e0+k (loaded by the caller one chunk ahead,
     // with ONE coalesced load each), handed to the owning lanes through the LDS crossbar: per-lane index loads
     // would put a second memory latency in front of every gather
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
-        v[u] = gather_row2<HD, BF>(A.PL, __shfl(srcv, u * G + gidx), cp);
+        v[u] = gather_row_n<HD, N, BF>(A.PL, __shfl(srcv, u * G + gidx), cp);
         sid[u] = __shfl(posv, u * G + gidx);
     }
     constexpr int P = UU > 8 ? 8 : UU;
@@ -648,70 +689,68 @@ __device__ __forceinline__ void bwd2_chunk(const EdgeBwdArgs& A, int e0, int e_e
     for (int p0 = 0; p0 < UU; p0 += P) {
         float al[P], ga_[P];
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const v2f t = ac2 * lrelu2(v[p0 + q] + pr, A.slope);
-            al[q] = t.x + t.y;
-        }
-        group_sum_n<D2, P>(al);
+        for (int q = 0; q < P; ++q) al[q] = hsum<N>(ac2 * lrelu_n<N>(v[p0 + q] + pr, A.slope));
+        group_sum_n<DL, P>(al);
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             al[q] = exp2_fast(al[q] - m2) * inv;
-            const v2f t = g * v[p0 + q];
-            ga_[q] = t.x + t.y;
+            ga_[q] = hsum<N>(g * v[p0 + q]);
         }
-        group_sum_n<D2, P>(ga_);
+        group_sum_n<DL, P>(ga_);
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             const int u = p0 + q;
             const int j = e0 + u * G + gidx;
             const bool valid = j < e_end_v;
             const float ge = valid ? al[q] * (ga_[q] - dot) : 0.f;   // padded slots contribute nothing
-            const v2f s = v[u] + pr;
-            const v2f sel = v2f{s.x > 0.f ? ac.x : acs.x, s.y > 0.f ? ac.y : acs.y};   // a * LReLU'(s)
-            const v2f gs = ge * sel;
-            ga += ge * lrelu2(s, A.slope);
+            const vnf<N> s = v[u] + pr;
+            const vnf<N> gs = ge * select_pos<N>(s, ac, acs);        // ge * a * LReLU'(s)
+            ga += ge * lrelu_n<N>(s, A.slope);
             gpr += gs;
-            const v2f msg = g * al[q] + gs;                      // d/dPL[src] from this edge
-            if (valid && DBG != 1) store_row2<HD, BF>(A.msg, sid[u], cp, msg);
+            const vnf<N> msg = g * al[q] + gs;                       // d/dPL[src] from this edge
+            if (valid && DBG != 1) store_row_n<HD, N, BF>(A.msg, sid[u], cp, msg);
         }
     }
 }
 
-template <int HD, int D, int DBG = 0, bool BF = false>
+template <int HD, int D, int N, int DBG = 0, bool BF = false>
 __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) {
-    constexpr int LPE = HD / 2, G = 64 / LPE, D2 = D / 2, H = HD / D;
+    constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
     constexpr int U = 16 / G;
     constexpr int CH = 16;
+    static_assert(D % N == 0 && U >= 1, "lane layout");
     __shared__ float red[4][HD];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cp = lane % LPE, gidx = lane / LPE;
-    const int c = 2 * cp;                                        // first of the lane's two channels
-    const v2f ac = *reinterpret_cast<const v2f*>(A.a + c);
-    const v2f acs = ac * A.slope;
-    const v2f ac2 = ac * kLog2e;
+    const int c = N * cp;                                        // first of the lane's channels
+    const vnf<N> ac = *reinterpret_cast<const vnf<N>*>(A.a + c);
+    const vnf<N> acs = ac * A.slope;
+    const vnf<N> ac2 = ac * kLog2e;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    v2f ga = v2f{0.f, 0.f};
+    vnf<N> ga = vzero<N>();
+    vnf<N> one, slp;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { one[i] = 1.0f; slp[i] = A.slope; }
 
     for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < A.n_items; it += nwaves) {
         const int4 item = A.items[it];
         const int64_t row = item.x;
         const int b = item.y, e_end = item.z, slot = item.w;
         const int e_end_v = per_lane(e_end);
-        const v2f hp = *reinterpret_cast<const v2f*>(A.hpre + row * HD + c);
-        const v2f dsel = v2f{hp.x > 0.f ? 1.0f : A.slope, hp.y > 0.f ? 1.0f : A.slope};
-        v2f g;
-        if (A.gh != nullptr) g = *reinterpret_cast<const v2f*>(A.gh + row * D + (c % D)) * dsel * (1.0f / (float)H);   // E:598-603
+        const vnf<N> hp = *reinterpret_cast<const vnf<N>*>(A.hpre + row * HD + c);
+        const vnf<N> dsel = select_pos<N>(hp, one, slp);
+        vnf<N> g;
+        if (A.gh != nullptr) g = *reinterpret_cast<const vnf<N>*>(A.gh + row * D + (c % D)) * dsel * (1.0f / (float)H);   // E:598-603
         else {
-            g = *reinterpret_cast<const v2f*>(A.g + row * HD + c);
+            g = *reinterpret_cast<const vnf<N>*>(A.g + row * HD + c);
             if (A.g_raw) g = g * dsel;                           // E:888-892 applied by the consumer
         }
-        const v2f pr = *reinterpret_cast<const v2f*>(A.PR + row * HD + c);
-        const v2f gh2 = g * hp;
-        const float dot = group_sum<D2>(gh2.x + gh2.y);
+        const vnf<N> pr = *reinterpret_cast<const vnf<N>*>(A.PR + row * HD + c);
+        const float dot = group_sum<DL>(hsum<N>(g * hp));
         const float m2 = A.mstat[row * H + c / D];
         const float inv = __builtin_amdgcn_rcpf(A.zstat[row * H + c / D] + 1e-8f);
-        v2f gpr = v2f{0.f, 0.f};
+        vnf<N> gpr = vzero<N>();
         // edge indices of a chunk: lane k < 16 holds edge e0+k (clamped into the item: no predicate needed)
         auto load_idx = [&](int e0, int& srcv, int& posv) {
             const int jl = e0 + (lane & (CH - 1));
@@ -725,23 +764,26 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) {
             int srcn = 0, posn = 0;
             if (e0 + CH < e_end) load_idx(e0 + CH, srcn, posn);      // next chunk's indices: in flight during this one
             if constexpr (U >= 2) {
-                if (e_end - e0 <= CH / 2) bwd2_chunk<HD, D, U / 2, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
-                else bwd2_chunk<HD, D, U, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
+                if (e_end - e0 <= CH / 2) bwd2_chunk<HD, D, N, U / 2, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
+                else bwd2_chunk<HD, D, N, U, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
             } else {
-                bwd2_chunk<HD, D, U, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
+                bwd2_chunk<HD, D, N, U, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
             }
             srcv = srcn; posv = posn;
         }
 #pragma unroll
-        for (int off = LPE; off < 64; off <<= 1) { gpr.x += __shfl_xor(gpr.x, off); gpr.y += __shfl_xor(gpr.y, off); }
+        for (int off = LPE; off < 64; off <<= 1) gpr += shfl_xor_n<N>(gpr, off);
         if (gidx == 0) {
             float* dst = slot < 0 ? A.gPR + row * HD + c : A.part_acc + (int64_t)slot * HD + c;   // segment partial -> fix kernel
-            *reinterpret_cast<v2f*>(dst) = gpr;
+            *reinterpret_cast<vnf<N>*>(dst) = gpr;
         }
     }
 #pragma unroll
-    for (int off = LPE; off < 64; off <<= 1) { ga.x += __shfl_xor(ga.x, off); ga.y += __shfl_xor(ga.y, off); }
-    if (gidx == 0) { red[wave][c] = ga.x; red[wave][c + 1] = ga.y; }
+    for (int off = LPE; off < 64; off <<= 1) ga += shfl_xor_n<N>(ga, off);
+    if (gidx == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[wave][c + i] = ga[i];
+    }
     __syncthreads();
     if (threadIdx.x < HD)
         A.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] =
@@ -890,6 +932,11 @@ static bool packed_layout() {
     static const bool v = [] { const char* e = getenv("GAT_PACKED"); return !(e && e[0] == '0'); }();
     return v;
 }
+// channels per lane of the packed kernels where the shape allows 4 (H*D >= 32, D % 4 == 0): GAT_CPL=2|4 (A/B)
+static int lane_channels() {
+    static const int v = [] { const char* e = getenv("GAT_CPL"); return (e && e[0] == '2') ? 2 : 4; }();
+    return v;
+}
 
 template <int HD, int D>
 int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
@@ -905,13 +952,23 @@ int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
     } else {
         bool launched = false;
         if constexpr (D % 2 == 0) {
-            if (packed_layout()) {                   // two channels per lane (see edge_fwd2_kernel)
+            if (packed_layout()) {                   // two or four channels per lane (see edge_fwd2_kernel)
                 // one wave per block: a 4-wave block lives as long as its longest item (a 256-edge segment next to
                 // 10-edge rows) and pins the other three wave slots meanwhile — 5.51 -> 5.02 ms per step
                 static const int wpb = [] { const char* e = getenv("GAT_FWD_WAVES"); const int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
                 const dim3 grid((unsigned)((a.n_items + wpb - 1) / wpb)), block(64 * wpb);
-                if (a.bf16) hipLaunchKernelGGL((edge_fwd2_kernel<HD, D, true>), grid, block, 0, s, a);
-                else hipLaunchKernelGGL((edge_fwd2_kernel<HD, D, false>), grid, block, 0, s, a);
+                bool four = false;
+                if constexpr (HD >= 32 && D % 4 == 0) {
+                    if (lane_channels() == 4) {
+                        if (a.bf16) hipLaunchKernelGGL((edge_fwd2_kernel<HD, D, 4, true>), grid, block, 0, s, a);
+                        else hipLaunchKernelGGL((edge_fwd2_kernel<HD, D, 4, false>), grid, block, 0, s, a);
+                        four = true;
+                    }
+                }
+                if (!four) {
+                    if (a.bf16) hipLaunchKernelGGL((edge_fwd2_kernel<HD, D, 2, true>), grid, block, 0, s, a);
+                    else hipLaunchKernelGGL((edge_fwd2_kernel<HD, D, 2, false>), grid, block, 0, s, a);
+                }
                 launched = true;
             }
         }
@@ -946,7 +1003,12 @@ struct BwdSel { bool store, taps, bf16; };
 template <int HD, int D, bool BF>
 const void* bwd_variant(bool store, bool taps) {
     if constexpr (D % 2 == 0) {
-        if (store && !taps && packed_backward()) return (const void*)edge_bwd2_kernel<HD, D, 0, BF>;
+        if (store && !taps && packed_backward()) {
+            if constexpr (HD >= 32 && D % 4 == 0) {
+                if (lane_channels() == 4) return (const void*)edge_bwd2_kernel<HD, D, 4, 0, BF>;
+            }
+            return (const void*)edge_bwd2_kernel<HD, D, 2, 0, BF>;
+        }
     }
     return store ? (taps ? (const void*)edge_bwd_kernel<HD, D, true, true, 0, BF> : (const void*)edge_bwd_kernel<HD, D, true, false, 0, BF>)
                  : (taps ? (const void*)edge_bwd_kernel<HD, D, false, true, 0, BF> : (const void*)edge_bwd_kernel<HD, D, false, false, 0, BF>);
@@ -968,8 +1030,18 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
     bool launched = false;
     if constexpr (D % 2 == 0) {
         if (store && !taps && packed_backward()) {
-            if (a.bf16) hipLaunchKernelGGL((edge_bwd2_kernel<HD, D, 0, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((edge_bwd2_kernel<HD, D, 0, false>), grid, block, 0, s, a);
+            bool four = false;
+            if constexpr (HD >= 32 && D % 4 == 0) {
+                if (lane_channels() == 4) {
+                    if (a.bf16) hipLaunchKernelGGL((edge_bwd2_kernel<HD, D, 4, 0, true>), grid, block, 0, s, a);
+                    else hipLaunchKernelGGL((edge_bwd2_kernel<HD, D, 4, 0, false>), grid, block, 0, s, a);
+                    four = true;
+                }
+            }
+            if (!four) {
+                if (a.bf16) hipLaunchKernelGGL((edge_bwd2_kernel<HD, D, 2, 0, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((edge_bwd2_kernel<HD, D, 2, 0, false>), grid, block, 0, s, a);
+            }
             launched = true;
         }
     }
