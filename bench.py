@@ -222,8 +222,7 @@ def main():
             if use_graph:
                 out = ctx.step()
             elif runner is None:
-                out = ctx.forward()
-                ctx.backward()
+                out = ctx.step()             # forward + head + loss + backward, loss / #correct read back once at the end
             else:
                 out = runner.step()
             return out
