@@ -104,12 +104,15 @@ __global__ __launch_bounds__(256) void head_forward_kernel(HeadArgs A, int32_t N
                 }
             }
             float sum = 0.f;
-            for (int c = 0; c < C; ++c) { const float ev = expf(zr[c] - mv); zr[c] = ev; sum += ev; }
+            // E:514 uses __expf (= ex2.approx(x * log2 e)): the hardware exp2 here, not the 10-instruction libm expf
+            for (int c = 0; c < C; ++c) { const float ev = __builtin_amdgcn_exp2f((zr[c] - mv) * 1.4426950408889634f); zr[c] = ev; sum += ev; }
             const double den = (double)sum + 1e-8;
+            const double rden = 1.0 / den;
             const int lab = A.labels[n];
             float best = -1.f; int pred = 0; float plab = 0.f;
             for (int c = 0; c < C; ++c) {
-                const float yv = (float)((double)zr[c] / den);
+                const float yv = (float)((double)zr[c] * rden);       // E:140 divides in double: one reciprocal + a product per class
+                                                                         // (47 fp64 divisions per node made this kernel VALU-bound)
                 zr[c] = yv;
                 if (c == 0 || yv > best) { best = yv; pred = c; }     // strict >, first max wins
                 if (c == lab) plab = yv;
