@@ -18,6 +18,7 @@
 // slabs summed in fixed order.
 #include "gat_internal.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -222,6 +223,98 @@ __global__ __launch_bounds__(256) void rowgemm_kernel(AS as, BS bs, EP ep, int64
     }
 }
 
+// The same product for K <= kKC (B resident in LDS for the whole block) with the A stream software-pipelined:
+// k is walked in steps of 32 (4 float4 per lane), the fragments of step q+1 — of this tile or of the block's next
+// tile — are in flight while step q is multiplied.  The all-at-once variant above needs 64 VGPRs of A fragments
+// next to 64 accumulator registers: 2 waves per SIMD, and every tile starts with an exposed load latency (MFMA
+// pipe 47-55 % busy, rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES).  Two 4-float4 buffers instead of one 16-float4 one.
+template <int NT, class AS, class BS, class EP>
+__global__ __launch_bounds__(256) void rowgemm_pipe_kernel(AS as, BS bs, EP ep, int64_t M, int32_t N, int32_t K) {
+    constexpr int NW = NT * 32;
+    extern __shared__ float Bsh[];                    // [kc8][NW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.y * NW;
+    const int64_t ntiles = (M + 127) / 128;
+    const int kc8 = (K + 7) & ~7;
+    if constexpr (BS::kAlongK) {
+        for (int idx = threadIdx.x; idx < kc8 * NW; idx += 256) {
+            const int kk = idx % kc8, j = idx / kc8;
+            Bsh[kk * NW + j] = (kk < K && n0 + j < N) ? bs.at(kk, n0 + j) : 0.f;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < kc8 * NW; idx += 256) {
+            const int kk = idx / NW, j = idx % NW;
+            Bsh[kk * NW + j] = (kk < K && n0 + j < N) ? bs.at(kk, n0 + j) : 0.f;
+        }
+    }
+    __syncthreads();
+    const int nsteps = (kc8 + 31) >> 5;
+    auto load_a = [&](int64_t tile, int step, float4 (&buf)[4]) {
+        const int64_t row = tile * 128 + wave * 32 + li;
+        const bool rvalid = row < M;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int kk = step * 32 + st * 8 + 4 * half;
+            buf[st] = (rvalid && kk < K) ? as.load4(row, kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    v16f acc[NT];
+    auto clear = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    };
+    auto mma = [&](int step, const float4 (&buf)[4]) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            if (step * 32 + st * 8 < kc8) {
+                const float* brow = Bsh + (step * 32 + st * 8 + 4 * half) * NW + li;
+                const float a4[4] = {buf[st].x, buf[st].y, buf[st].z, buf[st].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], brow[j * NW + nt * 32], acc[nt], 0, 0, 0);
+            }
+        }
+    };
+    auto store = [&](int64_t tile) {                  // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = tile * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int col = n0 + nt * 32 + li;
+                if (orow < M && col < N) ep(orow, col, acc[nt][r]);
+            }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int step = 0;
+    float4 b0[4], b1[4];
+    clear();
+    load_a(tile, 0, b0);
+    for (;;) {
+        int64_t t1 = tile; int s1 = step + 1;
+        if (s1 == nsteps) { s1 = 0; t1 = tile + gridDim.x; }
+        const bool more1 = t1 < ntiles;
+        if (more1) load_a(t1, s1, b1);
+        mma(step, b0);
+        if (step == nsteps - 1) { store(tile); clear(); }
+        if (!more1) break;
+        int64_t t2 = t1; int s2 = s1 + 1;
+        if (s2 == nsteps) { s2 = 0; t2 = t1 + gridDim.x; }
+        const bool more2 = t2 < ntiles;
+        if (more2) load_a(t2, s2, b0);
+        mma(s1, b1);
+        if (s1 == nsteps - 1) { store(t1); clear(); }
+        if (!more2) break;
+        tile = t2; step = s2;
+    }
+}
+
 template <class AS, class BS, class EP>
 int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, int32_t K, bool vec4, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -230,6 +323,24 @@ int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, 
     const int kc_lds = ((K < kKC ? K : kKC) + 7) & ~7;
     const size_t lds = (size_t)kc_lds * NW * sizeof(float);
     const int64_t ntiles = (M + 127) / 128;
+    if constexpr (!EP::kTwoPhase) {
+        static const bool pipe = [] { const char* e = getenv("GAT_GEMM_PIPE"); return !(e && e[0] == '0'); }();   // A/B
+        // only up to 64 output columns per block: with 128 (64 accumulator + 148 other registers = 2 waves per SIMD
+        // either way) the pipelined form measured 1.31 vs 1.22 ms per step for the projections; grad_x 0.56 -> 0.48
+        if (vec4 && K <= kKC && pipe && NT <= 2) {
+#define GAT_ROWGEMM_PIPE(NT_)                                                                                 \
+    {                                                                                                         \
+        auto kern = rowgemm_pipe_kernel<NT_, AS, BS, EP>;                                                     \
+        const int64_t res = resident_blocks((const void*)kern, lds);                                          \
+        const dim3 grid((unsigned)(ntiles < res ? ntiles : res), (unsigned)((N + NW - 1) / NW));              \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, as, bs, ep, M, N, K);                                \
+    }
+            if (NT == 2) GAT_ROWGEMM_PIPE(2) else GAT_ROWGEMM_PIPE(1)
+#undef GAT_ROWGEMM_PIPE
+            GAT_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     // persistent grid = exactly the blocks that are resident at once (registers + LDS, occupancy API):
     // a larger grid would run a second, partly filled round of 25-tile blocks
 #define GAT_ROWGEMM(NT_, V_)                                                                                  \
