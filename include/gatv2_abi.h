@@ -180,7 +180,9 @@ enum {
     GAT_TAP_HPRE = 3,       /* [N][H][D]             d_h[l] (E:422) */
     GAT_TAP_HOUT = 4,       /* [N][H*D] | [N][D]     d_layer_outputs[l] (E:449, 456) */
     GAT_TAP_Y = 5,          /* [N][C]                d_y (E:508) */
-    GAT_TAP_G = 6,          /* [N][H][D]             input_gradients[l] (E:601, 891) */
+    GAT_TAP_G = 6,          /* [N][H][D]             input_gradients[l] (E:601, 891).  The device keeps the factors of
+                                                      E:598-603 / E:888-892 unapplied (the edge backward applies them on
+                                                      load); the tap returns the reference's tensor */
     GAT_TAP_GE = 7,         /* [H][E]                grad_attn_score (E:693) */
     GAT_TAP_MAX = 8,        /* [H][N]                d_max_attn_score (E:356) */
     GAT_TAP_SUM = 9,        /* [H][N]                d_sum_score_exp (E:357) */
