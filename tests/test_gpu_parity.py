@@ -329,3 +329,40 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
             assert ok, (keep_taps, info)
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("env", [{"GAT_PACKED": "0"}, {"GAT_CPL": "2"}, {"GAT_BWD_ATOMICS": "1"},
+                                 {"GAT_FWD_WAVES": "4", "GAT_GPL_WAVES": "1", "GAT_SEG_EDGES": "64"}])
+def test_ab_switches_stay_correct(pkg, orc, env):
+    """The A/B switches of DESIGN §7 select other kernels / launch shapes for the SAME math: each must still
+    match the oracle (they are read once per process, hence a subprocess)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import __graft_entry__ as entry
+        from conftest import grad_close, small_graph
+        pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
+        rng = np.random.default_rng(5)
+        rp, ci = small_graph(rng, 260, 2600, hub=(9, 700), empty=(0, 3))
+        x = rng.standard_normal((260, 12)).astype(np.float32)
+        lab = rng.integers(0, 4, 260).astype(np.int32); lab[0] = 3
+        for heads, outdims in (([8, 8], [8, 8]), ([4, 2], [4, 8])):
+            cfg = orc.Config(heads, outdims, 12, 4)
+            W, a, Wo = orc.xavier_params(cfg, 6)
+            ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+            ctx = pkg.GatContext(heads, outdims, 12, 4)
+            ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
+            for g, arr in enumerate((W, a, Wo)): ctx.params_set(g, arr)
+            ctx.zero_grad(); loss, correct = ctx.step()
+            assert abs(loss - ref.loss_sum_f64) / 260 < 1e-4 and correct == ref.n_correct
+            assert np.abs(ctx.tap(A.TAP_HPRE, 1) - ref.taps["hpre"][1]).max() < 1e-4 * max(1.0, np.abs(ref.taps["hpre"][1]).max())
+            got = np.concatenate([ctx.grads_get(g) for g in range(3)])
+            ok, info = grad_close(got, np.concatenate([ref.gradW, ref.grada, ref.gradWo]), 1e-3)
+            assert ok, (heads, info)
+            ctx.close()
+        print("OK")
+    """)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
