@@ -435,18 +435,33 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
     for (int64_t t = 0; t < ntile; ++t) {
         const int buf = (int)(t & 1);
         if (t + 1 < ntile) load_tile(kb + (t + 1) * KT);
-#pragma unroll 4
-        for (int ks = 0; ks < KT / 2; ++ks) {
-            const int kk = ks * 2 + half;
-            float a[2], b[NY];
-            a[0] = As[buf][kk][wm * 64 + li]; a[1] = As[buf][kk][wm * 64 + 32 + li];
+        // LDS operands of step ks+1 are read before the MFMAs of step ks are issued: hipcc otherwise reloads the
+        // same two registers and waits lgkmcnt(0) in front of every MFMA group (LDS latency exposed, pipe 67 % busy)
+        float a[2], b[NY];
+        a[0] = As[buf][half][wm * 64 + li]; a[1] = As[buf][half][wm * 64 + 32 + li];
 #pragma unroll
-            for (int y = 0; y < NY; ++y) b[y] = Bs[buf][kk][wn * (NY * 32) + y * 32 + li];
+        for (int y = 0; y < NY; ++y) b[y] = Bs[buf][half][wn * (NY * 32) + y * 32 + li];
+#pragma unroll
+        for (int ks = 0; ks < KT / 2; ++ks) {
+            float an[2] = {0.f, 0.f}, bn[NY];
+#pragma unroll
+            for (int y = 0; y < NY; ++y) bn[y] = 0.f;
+            if (ks + 1 < KT / 2) {
+                const int kk = (ks + 1) * 2 + half;
+                an[0] = As[buf][kk][wm * 64 + li]; an[1] = As[buf][kk][wm * 64 + 32 + li];
+#pragma unroll
+                for (int y = 0; y < NY; ++y) bn[y] = Bs[buf][kk][wn * (NY * 32) + y * 32 + li];
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep the reads above the MFMAs (the scheduler sinks them to their use)
 #pragma unroll
             for (int x = 0; x < 2; ++x)
 #pragma unroll
                 for (int y = 0; y < NY; ++y)
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a[0] = an[0]; a[1] = an[1];
+#pragma unroll
+            for (int y = 0; y < NY; ++y) b[y] = bn[y];
         }
         if (t + 1 < ntile) store_tile(buf ^ 1);
         __syncthreads();
