@@ -147,3 +147,26 @@ def test_rccl_transport_needs_one_gpu_per_rank(pkg, tmp_path):
     r = run(["--dataset", "tiny", "--data-root", str(tmp_path), "--num-layers", "2", "--heads", "8,8", "--outdims", "8,8",
              "--epochs", "1", "--ranks", "2"])
     assert r.returncode == 1 and "needs that many GPUs" in r.stderr
+
+
+@pytest.mark.gpu
+def test_binary_cache_gives_the_same_run(pkg, tmp_path):
+    """--cache: the parsed text files are stored next to them; a second run loads the cache and must print the
+    same loss lines; touching a text file invalidates it."""
+    ds = pkg.synth.make_dataset("cora", scale=0.1)
+    pkg.synth.write_text_dataset(ds, str(tmp_path), "tiny")
+    args = ["--dataset", "tiny", "--data-root", str(tmp_path), "--num-layers", "2", "--heads", "8,8", "--outdims", "8,8",
+            "--epochs", "2", "--seed", "3", "--cache"]
+    pat = r"Avg Loss: ([0-9.]+), Accuracy: ([0-9.]+)%"
+    first = run(args)
+    assert first.returncode == 0, first.stderr
+    cache = tmp_path / "tiny" / "gatv2_cache.bin"
+    assert cache.exists() and cache.stat().st_size > ds["n"] * ds["f"] * 4
+    second = run(args)
+    assert second.returncode == 0 and re.findall(pat, first.stdout) == re.findall(pat, second.stdout)
+    assert f"Graph loaded: {ds['n']} nodes, {ds['e']} edges" in second.stdout
+    before = cache.stat().st_mtime_ns
+    os.utime(tmp_path / "tiny" / "labels.txt", (cache.stat().st_mtime + 3600, cache.stat().st_mtime + 3600))
+    third = run(args)                          # a text file newer than the cache: re-parsed and rewritten
+    assert third.returncode == 0 and re.findall(pat, first.stdout) == re.findall(pat, third.stdout)
+    assert cache.stat().st_mtime_ns > before
