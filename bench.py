@@ -292,7 +292,7 @@ def main():
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch_bytes} if timed else None,
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in stats.items() if v[0] > 0},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # CPU lines: rank 0 at N = 1 only (the other ranks would wait in the barrier)
             line["cpu_baseline"] = cpu_baseline(pkg, args.workload, heads, outdims, args.cpu_sample_scale)
             line["cpu_baseline_restructured"] = cpu_baseline_restructured(pkg, args.workload, heads, outdims)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
