@@ -92,6 +92,7 @@ struct gat_ctx {
     float* gPL = nullptr; bool gPL_bound = false;   // [n_table][HDmax]
     float* gPR = nullptr;                           // [n_rows][HDmax]
     float* gH = nullptr;                            // [n_rows][D_last] head-independent output gradient (HeadBwdArgs::gh_out)
+    bool y_valid = false;                           // c->y holds the last forward's probabilities (not after a fused head step)
     int32_t* csc_pos = nullptr;                     // [E] slot of each CSR edge in source-major order
     int32_t* csc_ptr = nullptr;                     // [n_table+1]
     int4* gpl_chunks = nullptr; int4* gpl_heavy = nullptr; float* gpl_part = nullptr;   // long source lists (HeavyList)
@@ -597,6 +598,7 @@ int gat_head_forward(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
         Scope t(c, GAT_K_HEAD_FWD);
         GAT_TRY(launch_head_forward(a, c->stream));
     }
+    c->y_valid = true;
     if (loss_sum || n_correct) {
         float hl = 0.f; int32_t hc = 0;
         GAT_HIP(hipMemcpyAsync(&hl, c->loss_out, sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -697,8 +699,32 @@ static int forward_phases(gat_ctx* c) {
     }
     return 0;
 }
-static int backward_phases(gat_ctx* c) {
-    GAT_TRY(gat_head_backward(c));
+static void head_args(gat_ctx* c, HeadArgs* f, HeadBwdArgs* b) {
+    const Layer& y = c->layers.back();
+    f->Wo = Wo_of(c); f->HL = y.hout; f->labels = c->labels; f->y = c->y;
+    f->loss_partial = c->loss_partial; f->correct_partial = c->correct_partial;
+    f->loss_out = c->loss_out; f->correct_out = c->correct_out;
+    f->n_rows = c->n_rows; f->C = c->cfg.num_classes; f->DL = y.D;
+    b->Wo = Wo_of(c); b->HL = y.hout; b->y = c->y; b->labels = c->labels; b->hpre = y.hpre; b->g = y.g; b->gh_out = c->gH;
+    b->gradWo = gWo_of(c); b->partial = c->hb_partial; b->n_rows = c->n_rows; b->C = c->cfg.num_classes;
+    b->DL = y.D; b->H = y.H; b->slope = c->cfg.negative_slope; b->flat_index = c->cfg.flat_lrelu_index;
+}
+// gat_step: the head's forward and backward as ONE kernel when nothing needs the class probabilities in HBM
+static bool fused_head(gat_ctx* c) {
+    if (c->cfg.keep_taps) return false;
+    HeadArgs f{}; HeadBwdArgs b{};
+    head_args(c, &f, &b);
+    return head_step_supported(b);
+}
+static int head_step(gat_ctx* c) {
+    HeadArgs f{}; HeadBwdArgs b{};
+    head_args(c, &f, &b);
+    Scope t(c, GAT_K_HEAD_BWD);
+    c->y_valid = false;
+    return launch_head_step(f, b, c->stream);
+}
+static int backward_phases(gat_ctx* c, bool head_done = false) {
+    if (!head_done) GAT_TRY(gat_head_backward(c));
     for (int l = c->cfg.num_layers - 1; l >= 0; --l) {
         GAT_TRY(gat_layer_backward_edges(c, l));
         if (c->comm && needs_exchange(c, l)) {
@@ -754,8 +780,13 @@ static void graph_drop(gat_ctx* c) {
 }
 static int step_body(gat_ctx* c) {
     GAT_TRY(forward_phases(c));
-    GAT_TRY(gat_head_forward(c, nullptr, nullptr));
-    GAT_TRY(backward_phases(c));
+    if (fused_head(c)) {
+        GAT_TRY(head_step(c));
+        GAT_TRY(backward_phases(c, true));
+    } else {
+        GAT_TRY(gat_head_forward(c, nullptr, nullptr));
+        GAT_TRY(backward_phases(c));
+    }
     return launch_pack_result(c->loss_out, c->correct_out, c->grads + c->nW + c->nA + c->nWo, c->stream);
 }
 static int step_graph(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
@@ -802,11 +833,8 @@ int gat_step_graph(gat_ctx* c, int32_t enable) {
 int gat_step(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
     GAT_TRY(check_step(c, "gat_step"));
     if (c->graph_state != 0) return step_graph(c, loss_sum, n_correct);
-    GAT_TRY(forward_phases(c));
-    GAT_TRY(gat_head_forward(c, nullptr, nullptr));
-    GAT_TRY(backward_phases(c));
+    GAT_TRY(step_body(c));                              // ends with the packed {loss, correct} behind the gradients
     const int64_t np = c->nW + c->nA + c->nWo;
-    GAT_TRY(launch_pack_result(c->loss_out, c->correct_out, c->grads + np, c->stream));
     if (c->comm) {
         Scope t(c, GAT_K_EXCHANGE);
         GAT_TRY(c->comm->all_reduce(c->grads, np + 3, c->stream));
@@ -953,7 +981,10 @@ int gat_tap(gat_ctx* c, int tensor, int32_t l, void* host, int64_t count) {
         case GAT_TAP_SUM: GAT_TRY(need(N * y.H)); return transposed(y.zstat, N, y.H, false);
         case GAT_TAP_HPRE: GAT_TRY(need(N * y.HD)); return d2h(c, host, y.hpre, N * y.HD * sizeof(float));
         case GAT_TAP_HOUT: { const int64_t n = N * (last ? y.D : y.HD); GAT_TRY(need(n)); return d2h(c, host, y.hout, n * sizeof(float)); }
-        case GAT_TAP_Y: GAT_TRY(need(N * c->cfg.num_classes)); return d2h(c, host, c->y, N * c->cfg.num_classes * sizeof(float));
+        case GAT_TAP_Y:
+            GAT_TRY(need(N * c->cfg.num_classes));
+            if (!c->y_valid) GAT_TRY(gat_head_forward(c, nullptr, nullptr));     // after a fused head step: y = f(H_L, Wo), both still there
+            return d2h(c, host, c->y, N * c->cfg.num_classes * sizeof(float));
         case GAT_TAP_G: {
             GAT_TRY(need(N * y.HD));
             if (last && c->gH) {                        // formed on the fly by the kernels: same expression, same order

@@ -312,6 +312,107 @@ __global__ __launch_bounds__(256) void head_backward2_kernel(HeadBwdArgs A, int3
     for (int i = tid; i < C * DL; i += 256) A.partial[(int64_t)blockIdx.x * C * DL + i] = s_tmp[i] + s_tmp[C * DL + i];
 }
 
+// Output head forward AND backward in one pass over the nodes (gat_step): logits, softmax, loss / #correct,
+// dz = y - onehot, gH = Wo^T dz, gradWo += dz^T H_L — the class probabilities never reach HBM (0.46 GB written
+// by head_forward_kernel and read back by head_backward2_kernel otherwise).  Same expressions in the same order
+// as those two kernels.  128-node tiles: waves 0-1 own a node each for the softmax and gH, waves 2-3 own
+// (class, half-tile) for gradWo.
+template <int DL>
+__global__ __launch_bounds__(256) void head_step_kernel(HeadArgs F, HeadBwdArgs A, int32_t ldz) {
+    constexpr int NB = 128;
+    extern __shared__ float lds[];
+    const int C = A.C;
+    float* s_wo = lds;                                   // [C][DL]
+    float* s_dz = s_wo + C * DL;                         // [NB][ldz]
+    float* s_hl = s_dz + NB * ldz;                       // [NB][DL]
+    __shared__ double s_loss[2];
+    __shared__ int32_t s_corr[2];
+    for (int i = threadIdx.x; i < C * DL; i += 256) s_wo[i] = A.Wo[i];
+    const int tid = threadIdx.x;
+    const int t2 = tid - 128;
+    const int wc = t2 >= 0 ? t2 % C : 0, whalf = t2 >= 0 ? t2 / C : 2;
+    float wacc[DL];
+#pragma unroll
+    for (int d = 0; d < DL; ++d) wacc[d] = 0.f;
+    double loss_acc = 0.0;
+    int corr_acc = 0;
+    const int64_t ntiles = (A.n_rows + NB - 1) / NB;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n0 = tile * NB;
+        const int rows_here = (int)((A.n_rows - n0 < NB) ? (A.n_rows - n0) : NB);
+        __syncthreads();                                 // previous tile fully consumed (and s_wo loaded)
+        if (tid < rows_here) {
+            const int64_t n = n0 + tid;
+            float x[DL];
+#pragma unroll
+            for (int j = 0; j < DL; ++j) { x[j] = A.HL[n * DL + j]; s_hl[tid * DL + j] = x[j]; }
+            float* zr = s_dz + tid * ldz;
+            float mv = -INFINITY;
+            for (int c = 0; c < C; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < DL; ++j) acc += s_wo[c * DL + j] * x[j];       // ascending j (E:496-498)
+                zr[c] = acc;
+                mv = fmaxf(mv, acc);
+            }
+            float sum = 0.f;
+            for (int c = 0; c < C; ++c) { const float ev = __builtin_amdgcn_exp2f((zr[c] - mv) * 1.4426950408889634f); zr[c] = ev; sum += ev; }
+            const double rden = 1.0 / ((double)sum + 1e-8);
+            const int lab = A.labels[n];
+            float best = -1.f; int pred = 0; float plab = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float yv = (float)((double)zr[c] * rden);
+                if (c == 0 || yv > best) { best = yv; pred = c; }      // strict >, first max wins
+                if (c == lab) plab = yv;
+                zr[c] = yv - (c == lab ? 1.0f : 0.0f);                 // dz
+            }
+            loss_acc += (double)(-logf(fmaxf(plab, 1e-12f)));
+            corr_acc += (pred == lab) ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            if (tid < rows_here) {
+                float acc[DL];
+#pragma unroll
+                for (int d = 0; d < DL; ++d) acc[d] = 0.f;
+                const float* zr = s_dz + tid * ldz;
+                for (int c = 0; c < C; ++c) {
+                    const float z = zr[c];
+#pragma unroll
+                    for (int d = 0; d < DL; ++d) acc[d] += s_wo[c * DL + d] * z;
+                }
+                float* out = A.gh_out + (n0 + tid) * DL;
+#pragma unroll
+                for (int d = 0; d < DL; ++d) out[d] = acc[d];
+            }
+        } else if (whalf < 2) {
+            const int r0 = whalf * 64, r1 = (r0 + 64 < rows_here) ? r0 + 64 : rows_here;
+            for (int r = r0; r < r1; ++r) {
+                const float z = s_dz[r * ldz + wc];
+#pragma unroll
+                for (int d = 0; d < DL; ++d) wacc[d] += z * s_hl[r * DL + d];
+            }
+        }
+    }
+    __syncthreads();
+    float* s_tmp = s_dz;                                 // [2][C][DL]
+    if (whalf < 2) {
+#pragma unroll
+        for (int d = 0; d < DL; ++d) s_tmp[(whalf * C + wc) * DL + d] = wacc[d];
+    }
+    for (int off = 32; off > 0; off >>= 1) {             // loss / #correct live in waves 0-1
+        loss_acc += __shfl_down(loss_acc, off);
+        corr_acc += __shfl_down(corr_acc, off);
+    }
+    if (tid < 128 && (tid & 63) == 0) { s_loss[tid >> 6] = loss_acc; s_corr[tid >> 6] = corr_acc; }
+    __syncthreads();
+    for (int i = tid; i < C * DL; i += 256) A.partial[(int64_t)blockIdx.x * C * DL + i] = s_tmp[i] + s_tmp[C * DL + i];
+    if (tid == 0) {
+        F.loss_partial[blockIdx.x] = s_loss[0] + s_loss[1];
+        F.correct_partial[blockIdx.x] = s_corr[0] + s_corr[1];
+    }
+}
+
 // ---- optimizer / clip (E:146-177, 250-278, 896-923) ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, float lr, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,6 +512,28 @@ int launch_head_forward(const HeadArgs& a, hipStream_t s) {
                        a.loss_out, a.correct_out);
     GAT_HIP(hipGetLastError());
     return 0;
+}
+bool head_step_supported(const HeadBwdArgs& b) {
+    return b.g == nullptr && b.gh_out != nullptr && b.C <= 64 && (b.DL == 4 || b.DL == 8 || b.DL == 16);
+}
+int launch_head_step(const HeadArgs& f, const HeadBwdArgs& b, hipStream_t s) {
+    if (!head_step_supported(b)) return fail(GAT_E_UNSUPPORTED, "head_step: shape outside the fused kernel");
+    const int ldz = (b.C % 2 == 0) ? b.C + 1 : b.C;
+    const size_t lds = ((size_t)b.C * b.DL + (size_t)128 * (ldz + b.DL)) * sizeof(float);
+    int blocks = std::min(head_blocks(b.n_rows), head_bwd_blocks(b.n_rows, b.C, b.DL));      // both partial buffers
+    const void* fn = b.DL == 4 ? (const void*)head_step_kernel<4> : b.DL == 8 ? (const void*)head_step_kernel<8>
+                                                                                : (const void*)head_step_kernel<16>;
+    const int64_t res = resident_blocks(fn, lds);
+    if (res < blocks) blocks = (int)res;
+    if (blocks < 1) blocks = 1;
+    if (b.DL == 4) hipLaunchKernelGGL(head_step_kernel<4>, dim3(blocks), dim3(256), lds, s, f, b, ldz);
+    else if (b.DL == 8) hipLaunchKernelGGL(head_step_kernel<8>, dim3(blocks), dim3(256), lds, s, f, b, ldz);
+    else hipLaunchKernelGGL(head_step_kernel<16>, dim3(blocks), dim3(256), lds, s, f, b, ldz);
+    GAT_HIP(hipGetLastError());
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(64), 0, s, f.loss_partial, f.correct_partial, blocks,
+                       f.loss_out, f.correct_out);
+    GAT_HIP(hipGetLastError());
+    return launch_reduce_partials_add(b.partial, blocks, (int64_t)b.C * b.DL, b.gradWo, s);
 }
 int launch_pack_result(const float* loss, const int32_t* correct, float* dst3, hipStream_t s) {
     hipLaunchKernelGGL(pack_result_kernel, dim3(1), dim3(64), 0, s, loss, correct, dst3);

@@ -213,6 +213,9 @@ struct HeadBwdArgs {
 };
 int head_bwd_blocks(int64_t n_rows, int32_t C, int32_t DL);
 int launch_head_backward(const HeadBwdArgs& a, hipStream_t s);
+// forward + backward of the output head in one kernel (gat_step; y is not stored)
+bool head_step_supported(const HeadBwdArgs& b);
+int launch_head_step(const HeadArgs& f, const HeadBwdArgs& b, hipStream_t s);
 
 int launch_sgd(float* p, const float* g, float lr, int64_t n, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, float lr, int64_t n, float b1, float b2,
