@@ -63,9 +63,20 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(pkg, workload, heads, outdims, sample_scale):
     """Literal reference algorithm (per-edge W·x recomputation, O(deg^2) softmax backward) on the
     host cores, on a scaled-down graph of the same law.  Reported, never the target."""
+    os.environ["GAT_ORACLE_NATIVE"] = "1"      # BASELINE.md §3 flags, compiled on this machine (oracle/Makefile)
     orc = entry.load_oracle()
     n_full, e_full, f, c, kind = pkg.synth.SHAPES[workload]
 
@@ -85,8 +96,10 @@ def cpu_baseline(pkg, workload, heads, outdims, sample_scale):
     ds, t = run(sample_scale)
     return {
         "value": ds["e"] / t, "unit": "edges/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
+        "cpu_model": cpu_model(), "build_flags": orc.build_flags(),
         "sample": f"{workload}-law graph scaled to {ds['n']} nodes / {ds['e']} edges / {ds['f']} feat, "
-                  f"1 step fwd+bwd in {t:.2f} s (oracle literal mode, OpenMP)",
+                  f"1 step fwd+bwd in {t:.2f} s (oracle literal mode, OpenMP); the literal algorithm's softmax backward is "
+                  f"O(sum deg^2), which grows faster than E: the full graph would run at FEWER edges/s than this sample",
     }
 
 
@@ -111,6 +124,7 @@ def cpu_baseline_restructured(pkg, workload, heads, outdims):
         ds, t = run(scale)
     return {
         "value": ds["e"] / t, "unit": "edges/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
+        "cpu_model": cpu_model(), "build_flags": orc.build_flags(),
         "sample": f"{workload}-law graph scaled to {ds['n']} nodes / {ds['e']} edges / {ds['f']} feat, 1 step fwd+bwd in "
                   f"{t:.2f} s (restructured algorithm = the HIP path's, OpenMP; not the reference's kernels)",
     }
@@ -239,12 +253,19 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize(dev)
 
+        # per-step HIP events on the context's stream (median of the timed steps); recorded without a
+        # host sync, read after the closing fence.  `value` stays the wall-clock total of the bracketed region.
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            ev[i][0].record(stream)
             loss, correct = step()
+            ev[i][1].record(stream)
         fence()
         dt = time.perf_counter() - t0
+        step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+        median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
         stats = ctx.kernel_stats()
         bytes_step, bytes_k = ctx.algorithmic_bytes()
 
@@ -271,7 +292,8 @@ def main():
             "metric": "edges/sec (fwd+bwd, 2-layer 8-head GATv2)" if len(heads) == 2 else
                       f"edges/sec (fwd+bwd, {len(heads)}-layer 8-head GATv2)",
             "value": e / (dt / args.steps), "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "warmup": args.warmup, "ms_per_step": ms, "ms_per_step_median_hipevents": median_ms,
+            "ms_per_step_min_max_hipevents": [step_ms[0], step_ms[-1]], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "f32 arithmetic, bf16 PL/message storage",
             "data": "synthetic",
             "config": {

@@ -49,7 +49,7 @@ class _Config(C.Structure):
 PARAM_W, PARAM_A, PARAM_WO = 0, 1, 2
 TABLE_PL, TABLE_GPL = 0, 1
 (TAP_SRC, TAP_DST, TAP_ALPHA, TAP_HPRE, TAP_HOUT, TAP_Y, TAP_G, TAP_GE, TAP_MAX, TAP_SUM, TAP_PL,
- TAP_PR) = range(12)
+ TAP_PR, TAP_SCORE, TAP_GALPHA, TAP_GX) = range(15)
 (K_PROJECT, K_EDGE_FWD, K_HEAD_FWD, K_HEAD_BWD, K_EDGE_BWD, K_GPL_SUM, K_GRAD_W, K_GRAD_X, K_MISC,
  K_EXCHANGE, K_COUNT) = range(11)
 COMM_ID_BYTES = 128
@@ -150,6 +150,7 @@ def _declare(lib: C.CDLL) -> None:
         "gat_kernel_stats": [vp, C.c_int, P(i64), P(C.c_double)],
         "gat_kernel_stats_reset": [vp],
         "gat_algorithmic_bytes": [vp, P(C.c_double), P(C.c_double)],
+        "gat_algorithmic_bytes_shape": [P(_Config), i64, i64, i64, i32, P(C.c_double), P(C.c_double)],
     }
     for name, argt in sigs.items():
         fn = getattr(lib, name)          # AttributeError here == symbol missing from the .so
@@ -411,6 +412,8 @@ class GatContext:
             TAP_HOUT: ((N, D if last else H * D), np.float32),
             TAP_Y: ((N, self.C), np.float32),
             TAP_PL: ((self.n_table, H * D), np.float32), TAP_PR: ((N, H * D), np.float32),
+            TAP_SCORE: ((H, E), np.float32), TAP_GALPHA: ((H, E), np.float32),
+            TAP_GX: ((N, self.heads[l - 1] * self.outdims[l - 1] if l > 0 else 0), np.float32),
         }
         shape, dt = shapes[tensor]
         out = np.empty(shape, dt)
@@ -434,6 +437,24 @@ class GatContext:
         per = (C.c_double * K_COUNT)()
         _chk(self.lib.gat_algorithmic_bytes(self._ctx, C.byref(tot), per))
         return tot.value, {self.lib.gat_kernel_name(k).decode(): per[k] for k in range(K_COUNT)}
+
+
+def algorithmic_bytes_shape(heads: Sequence[int], outdims: Sequence[int], in_dim: int, num_classes: int, n_rows: int,
+                            n_edges: int, *, dtype: str = "f32", n_table: Optional[int] = None, replicated_input: bool = False):
+    """SURVEY 8d's algorithmic HBM bytes of one forward+backward step from the shape alone (host arithmetic: works
+    without a GPU).  -> (bytes_step, {kernel class: bytes})"""
+    lib = load_library()
+    L = len(heads)
+    h = (C.c_int32 * L)(*heads); d = (C.c_int32 * L)(*outdims)
+    cfg = _Config()
+    cfg.num_layers, cfg.heads, cfg.outdims = L, h, d
+    cfg.in_dim, cfg.num_classes = int(in_dim), int(num_classes)
+    cfg.storage_dtype = 1 if dtype == "bf16" else 0
+    tot = C.c_double()
+    per = (C.c_double * K_COUNT)()
+    _chk(lib.gat_algorithmic_bytes_shape(C.byref(cfg), n_rows, n_edges, n_rows if n_table is None else n_table,
+                                         int(replicated_input), C.byref(tot), per))
+    return tot.value, {lib.gat_kernel_name(k).decode(): per[k] for k in range(K_COUNT)}
 
 
 def mem_info():

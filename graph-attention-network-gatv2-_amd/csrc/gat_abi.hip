@@ -30,6 +30,8 @@ struct Layer {
     float* hout = nullptr;    // [n_rows][HD] / last: [n_rows][D]
     float* g = nullptr;       // [n_rows][HD]   dL/dh_pre (input_gradients[l], E:1339)
     float* ge = nullptr;      // [E][H]  (keep_taps)
+    float* score = nullptr;   // [E][H]  (keep_taps) raw attention scores, E:323
+    float* galpha = nullptr;  // [E][H]  (keep_taps) grad wrt attn_coeff, E:646
     float* mstat = nullptr;   // [n_rows][H] (keep_taps)
     float* zstat = nullptr;
 };
@@ -83,6 +85,7 @@ struct gat_ctx {
     float* params = nullptr;   // [W | a | Wo]
     float* grads = nullptr;    // [gradW | grada | gradWo] + 4 floats of tail: [loss, correct lo, correct hi, -]
     std::unique_ptr<gat::Comm> comm;                // exchange transport of a shard (gat_comm_init_*)
+    float* grads_prev = nullptr;                    // [n_params] with a transport: what the buffer held before this step (see reduce_begin)
     // gat_step as a replayed hipGraph (gat_step_graph): 0 off, 1 armed (next step runs eagerly, then captures), 2 ready
     int graph_state = 0, graph_warm = 0;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
@@ -208,7 +211,11 @@ static int ensure_buffers(gat_ctx* c) {
         if (l < L - 1 || c->cfg.flat_lrelu_index) GAT_TRY(dalloc(c, &y.g, N * y.HD));
         GAT_TRY(dalloc(c, &y.mstat, N * y.H));
         GAT_TRY(dalloc(c, &y.zstat, N * y.H));
-        if (c->cfg.keep_taps) GAT_TRY(dalloc(c, &y.ge, E * y.H));
+        if (c->cfg.keep_taps) {
+            GAT_TRY(dalloc(c, &y.ge, E * y.H));
+            GAT_TRY(dalloc(c, &y.score, E * y.H));
+            GAT_TRY(dalloc(c, &y.galpha, E * y.H));
+        }
     }
     if (!c->gPL_bound) GAT_TRY(dalloc(c, &c->gPL, T * c->HDmax));
     GAT_TRY(dalloc(c, &c->gPR, N * c->HDmax));
@@ -577,7 +584,7 @@ int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
     Layer& y = c->layers[l];
     EdgeFwdArgs a{};
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
-    a.alpha = y.alpha; a.hpre = y.hpre; a.hout = y.hout; a.mstat = y.mstat; a.zstat = y.zstat;
+    a.alpha = y.alpha; a.score = y.score; a.hpre = y.hpre; a.hout = y.hout; a.mstat = y.mstat; a.zstat = y.zstat;
     a.n_rows = c->n_rows; a.n_table = c->n_table; a.bf16 = bf16(c); a.H = y.H; a.D = y.D; a.is_last = (l == c->cfg.num_layers - 1);
     a.slope = c->cfg.negative_slope;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots; a.n_split = c->work.n_split;
@@ -632,7 +639,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     EdgeBwdArgs a{};
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
     a.alpha = y.alpha; a.mstat = y.mstat; a.zstat = y.zstat;
-    a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge;
+    a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge; a.galpha = y.galpha;
     a.g_raw = l < c->cfg.num_layers - 1;           // hidden layers: written by launch_grad_x without the LReLU' factor
     a.gh = (l == c->cfg.num_layers - 1) ? c->gH : nullptr;
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
@@ -758,14 +765,33 @@ int gat_forward(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
     }
     return read_result_tail(c, loss_sum, n_correct);
 }
+// The gradient buffer ACCUMULATES until gat_zero_grad (E:1262-1266, 1631-1633).  With a transport the step's
+// contribution must be summed over shards exactly once: the accumulated (already reduced) values are set
+// aside, the step runs into a zeroed buffer, that is all-reduced, and the old values are added back —
+// without this, a second step before gat_zero_grad would reduce the earlier sums again (x world).
+static int reduce_begin(gat_ctx* c) {
+    if (!c->comm) return 0;
+    const int64_t np = c->nW + c->nA + c->nWo;
+    if (!c->grads_prev) GAT_TRY(dalloc(c, &c->grads_prev, np));
+    Scope t(c, GAT_K_MISC);
+    GAT_HIP(hipMemcpyAsync(c->grads_prev, c->grads, (size_t)np * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    GAT_HIP(hipMemsetAsync(c->grads, 0, (size_t)np * sizeof(float), c->stream));
+    return 0;
+}
+static int reduce_end(gat_ctx* c, int64_t count) {          // count: n_params, or n_params + 3 with the result tail
+    if (!c->comm) return 0;
+    {
+        Scope t(c, GAT_K_EXCHANGE);
+        GAT_TRY(c->comm->all_reduce(c->grads, count, c->stream));
+    }
+    Scope t(c, GAT_K_MISC);
+    return launch_reduce_partials_add(c->grads_prev, 1, c->nW + c->nA + c->nWo, c->grads, c->stream);
+}
 int gat_backward(gat_ctx* c) {
     GAT_TRY(check_step(c, "gat_backward"));
+    GAT_TRY(reduce_begin(c));
     GAT_TRY(backward_phases(c));
-    if (c->comm) {
-        Scope t(c, GAT_K_EXCHANGE);
-        GAT_TRY(c->comm->all_reduce(c->grads, c->nW + c->nA + c->nWo, c->stream));
-    }
-    return 0;
+    return reduce_end(c, c->nW + c->nA + c->nWo);
 }
 // The whole step as ONE graph launch: small graphs (Cora / Pubmed / Arxiv shapes) are launch-bound — ~25
 // kernels of a few microseconds each — so the sequence is captured once from the context's stream and
@@ -833,12 +859,9 @@ int gat_step_graph(gat_ctx* c, int32_t enable) {
 int gat_step(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
     GAT_TRY(check_step(c, "gat_step"));
     if (c->graph_state != 0) return step_graph(c, loss_sum, n_correct);
+    GAT_TRY(reduce_begin(c));
     GAT_TRY(step_body(c));                              // ends with the packed {loss, correct} behind the gradients
-    const int64_t np = c->nW + c->nA + c->nWo;
-    if (c->comm) {
-        Scope t(c, GAT_K_EXCHANGE);
-        GAT_TRY(c->comm->all_reduce(c->grads, np + 3, c->stream));
-    }
+    GAT_TRY(reduce_end(c, c->nW + c->nA + c->nWo + 3));
     if (!loss_sum && !n_correct) return 0;
     return read_result_tail(c, loss_sum, n_correct);
 }
@@ -978,6 +1001,12 @@ int gat_tap(gat_ctx* c, int tensor, int32_t l, void* host, int64_t count) {
             return 0;
         }
         case GAT_TAP_GE: GAT_TRY(need(E * y.H)); return transposed(y.ge, E, y.H, true);
+        case GAT_TAP_SCORE: GAT_TRY(need(E * y.H)); return transposed(y.score, E, y.H, true);
+        case GAT_TAP_GALPHA: GAT_TRY(need(E * y.H)); return transposed(y.galpha, E, y.H, true);
+        case GAT_TAP_GX:                              // what launch_grad_x of layer l left in layer l-1's g buffer
+            if (l < 1) return fail(GAT_E_INVALID, "gat_tap: GAT_TAP_GX exists for layers >= 1 (E:1528 skips layer 0)");
+            GAT_TRY(need(N * y.F));
+            return d2h(c, host, c->layers[l - 1].g, N * y.F * sizeof(float));
         case GAT_TAP_SUM: GAT_TRY(need(N * y.H)); return transposed(y.zstat, N, y.H, false);
         case GAT_TAP_HPRE: GAT_TRY(need(N * y.HD)); return d2h(c, host, y.hpre, N * y.HD * sizeof(float));
         case GAT_TAP_HOUT: { const int64_t n = N * (last ? y.D : y.HD); GAT_TRY(need(n)); return d2h(c, host, y.hout, n * sizeof(float)); }
@@ -1151,28 +1180,40 @@ int gat_kernel_stats_reset(gat_ctx* c) {
     return 0;
 }
 
-int gat_algorithmic_bytes(gat_ctx* c, double* bytes_step, double* per_kernel) {
-    if (!c || !c->have_graph) return fail(GAT_E_STATE, "graph not set");
-    // every tensor the restructured algorithm must move once, fp32 (b = 4).
+// SURVEY §8(d), literally: every tensor the restructured algorithm must move once per step, with
+// b = storage bytes (4 fp32 / 2 bf16) on every float term — the single figure `roofline.achieved` is quoted
+// against.  It is a property of the WORKLOAD, not of this implementation: it counts the alpha write/read
+// (E*H per direction) although the training path recomputes alpha from the softmax stats instead, it counts
+// the gPL scatter once although the no-atomics scatter stores and re-reads a per-edge record, and in bf16 mode
+// it prices PR / h_pre / g at 2 bytes although they are kept in fp32 here.  Pure host arithmetic (no device).
+int gat_algorithmic_bytes_shape(const gat_config* cfg, int64_t n_rows, int64_t n_edges, int64_t n_table,
+                                int32_t replicated_input, double* bytes_step, double* per_kernel) {
+    if (!cfg || !cfg->heads || !cfg->outdims || cfg->num_layers <= 0) return fail(GAT_E_INVALID, "gat_algorithmic_bytes_shape: bad config");
     double k[GAT_K_COUNT] = {0};
-    const double N = (double)c->n_rows, E = (double)c->n_edges, b = 4.0;
-    const int L = c->cfg.num_layers;
+    const double N = (double)n_rows, E = (double)n_edges;
+    const double b = cfg->storage_dtype == GAT_DTYPE_BF16 ? 2.0 : 4.0;
+    const int L = cfg->num_layers;
     for (int l = 0; l < L; ++l) {
-        const Layer& y = c->layers[l];
-        const double HD = y.HD, H = y.H, F = y.F, Dout = (l == L - 1) ? y.D : y.HD;
-        const double NL = (l == 0 && c->Xtab) ? (double)c->n_table : N;     // rows of the W_left half
-        k[GAT_K_PROJECT] += b * (std::max(N, NL) * F + 2 * HD * F + (N + NL) * HD);
-        k[GAT_K_EDGE_FWD] += 4 * (N + 1) + 4 * E + b * (E * HD + N * HD + E * H + N * HD + N * Dout);
-        k[GAT_K_EDGE_BWD] += 4 * (N + 1) + 4 * E + b * (N * HD + E * HD + N * HD + E * H + E * HD + N * HD);
-        k[GAT_K_GRAD_W] += b * ((N + NL) * HD + std::max(N, NL) * F + 2 * HD * F);
-        if (l > 0) k[GAT_K_GRAD_X] += b * (2 * N * HD + 2 * N * F);
+        const double H = cfg->heads[l], D = cfg->outdims[l], HD = H * D;
+        const double F = l == 0 ? (double)cfg->in_dim : (double)cfg->heads[l - 1] * cfg->outdims[l - 1];
+        const double Dout = (l == L - 1) ? D : HD;
+        const double NL = (l == 0 && replicated_input) ? (double)n_table : N;     // rows of the W_left half (shards)
+        k[GAT_K_PROJECT] += b * (std::max(N, NL) * F + 2 * HD * F + (N + NL) * HD);          // X, W read; PL + PR written
+        k[GAT_K_EDGE_FWD] += 4 * (N + 1) + 4 * E + b * (E * HD + N * HD + E * H + N * HD + N * Dout);   // PL[src], PR, alpha, h_pre, H
+        k[GAT_K_EDGE_BWD] += 4 * (N + 1) + 4 * E + b * (N * HD + E * HD + N * HD + E * H + E * HD + N * HD);   // g, PL[src], PR, alpha, gPL scatter, gPR
+        k[GAT_K_GRAD_W] += b * ((N + NL) * HD + std::max(N, NL) * F + 2 * HD * F);            // gPL + gPR re-read, X, grad_W
+        if (l > 0) k[GAT_K_GRAD_X] += b * (2 * N * HD + 2 * N * F);                            // gPL + gPR, gX write, h_pre_{l-1}
     }
-    const double head = 2.0 * 4.0 * N * ((double)c->layers.back().D + 2.0 * c->cfg.num_classes + 2.0);
+    const double head = 2.0 * 4.0 * N * ((double)cfg->outdims[L - 1] + 2.0 * cfg->num_classes + 2.0);
     k[GAT_K_HEAD_FWD] = head / 2; k[GAT_K_HEAD_BWD] = head / 2;
     double tot = 0;
     for (int i = 0; i < GAT_K_COUNT; ++i) { tot += k[i]; if (per_kernel) per_kernel[i] = k[i]; }
     if (bytes_step) *bytes_step = tot;
     return 0;
+}
+int gat_algorithmic_bytes(gat_ctx* c, double* bytes_step, double* per_kernel) {
+    if (!c || !c->have_graph) return fail(GAT_E_STATE, "graph not set");
+    return gat_algorithmic_bytes_shape(&c->cfg, c->n_rows, c->n_edges, c->n_table, c->Xtab != nullptr, bytes_step, per_kernel);
 }
 
 }  // extern "C"

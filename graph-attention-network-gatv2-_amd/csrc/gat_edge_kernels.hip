@@ -27,6 +27,7 @@ namespace gat {
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
@@ -239,6 +240,9 @@ __device__ __forceinline__ void fwd_chunk(const EdgeFwdArgs& A, int e0, int e_en
         const int j = e0 + u * G + gidx;
         sc[u] = (j < e_end_v) ? t[u] : -INFINITY;
         cm = fmaxf(cm, sc[u]);
+        if constexpr (ALPHA) {                       // tap: the reference's attn_score (natural-log domain, E:323)
+            if (A.score != nullptr && (c % D) == 0 && j < e_end_v) A.score[(int64_t)j * H + c / D] = t[u] * kLn2;
+        }
     }
     const float mn = fmaxf(m, cm);
     const float scale = exp2_fast(m - mn);
@@ -421,7 +425,10 @@ __device__ __forceinline__ void bwd_chunk(const EdgeBwdArgs& A, int e0, int e_en
                 else unsafeAtomicAdd(A.gPL + (int64_t)sid[u] * HD + c, msg);
             }
             if constexpr (TAPS) {
-                if (valid && (c % D) == 0) A.ge[(int64_t)j * H + c / D] = ge;
+                if (valid && (c % D) == 0) {
+                    A.ge[(int64_t)j * H + c / D] = ge;
+                    if (A.galpha != nullptr) A.galpha[(int64_t)j * H + c / D] = ga_[q];
+                }
             }
         }
     }
@@ -619,7 +626,8 @@ __global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
         const int jl = e0 + (lane & (CH - 1));
         return A.col_idx[jl < e_end ? jl : e_end - 1];
     };
-    int srcv = load_idx(b);
+    int srcv = 0;
+    if (b < e_end) srcv = load_idx(b);               // empty item (zero in-degree row): e_end - 1 would be b - 1, i.e. -1 for row 0
     for (int e0 = b; e0 < e_end; e0 += CH) {
         const int srcn = (e0 + CH < e_end) ? load_idx(e0 + CH) : 0;
         if constexpr (U >= 2) {
@@ -758,8 +766,8 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) {
             srcv = A.col_idx[jlc];
             posv = (DBG == 2) ? jlc : A.pos[jlc];
         };
-        int srcv, posv;
-        load_idx(b, srcv, posv);
+        int srcv = 0, posv = 0;
+        if (b < e_end) load_idx(b, srcv, posv);                      // empty item: nothing to prefetch (e_end - 1 < b)
         for (int e0 = b; e0 < e_end; e0 += CH) {
             int srcn = 0, posn = 0;
             if (e0 + CH < e_end) load_idx(e0 + CH, srcn, posn);      // next chunk's indices: in flight during this one
@@ -827,6 +835,7 @@ __global__ __launch_bounds__(64) void edge_fwd_generic(EdgeFwdArgs A) {
                     s += A.a[ch] * lrelu(A.PL[sid * HD + ch] + A.PR[row * HD + ch], slope);
                 }
                 A.alpha[(int64_t)e * H + h] = s;
+                if (A.score != nullptr) A.score[(int64_t)e * H + h] = s;
                 m = fmaxf(m, s);
             }
             float Z = 0.f;
@@ -896,6 +905,7 @@ __global__ __launch_bounds__(64) void edge_bwd_generic(EdgeBwdArgs A) {
                 s_ge[h] = ge;
                 s_al[h] = al;
                 if (A.ge != nullptr) A.ge[(int64_t)e * H + h] = ge;
+                if (A.galpha != nullptr) A.galpha[(int64_t)e * H + h] = t;
             }
             __syncthreads();
             for (int ch = lane; ch < HD; ch += 64) {

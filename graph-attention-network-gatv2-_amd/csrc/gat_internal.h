@@ -37,6 +37,7 @@ struct EdgeFwdArgs {
     const float* PR;          // [n_rows][HD]
     const float* a;           // [HD]
     float* alpha;             // [E][H]; fast path: null = do not materialise (training path)
+    float* score;             // [E][H] or null: raw attention scores (tap, E:323); only with alpha
     float* hpre;              // [n_rows][HD]
     float* hout;              // hidden [n_rows][HD]; last [n_rows][D]
     float* mstat;             // [n_rows][H] softmax max per (row, head); fast path: log2 domain
@@ -91,6 +92,7 @@ struct EdgeBwdArgs {
     float* msg;               // [E][HD] message rows by slot (store path; summed by launch_gpl_sum)
     float* gPR;               // [n_rows][HD]   written
     float* ge;                // [E][H] or null (tap)
+    float* galpha;            // [E][H] or null (tap, E:646); only with ge
     float* ga_partial;        // [ga_blocks][HD] written
     int32_t ga_blocks;        // grid size the launcher must use (== rows of ga_partial)
     int64_t n_rows;

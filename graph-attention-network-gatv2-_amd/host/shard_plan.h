@@ -39,8 +39,10 @@ inline std::vector<int64_t> edge_balanced_bounds(const int32_t* row_ptr, int64_t
         b[p] = std::lower_bound(row_ptr, row_ptr + n + 1, target,
                                 [](int32_t v, double t) { return (double)v < t; }) - row_ptr;
     }
-    for (int p = 1; p <= world; ++p) b[p] = std::max(b[p], b[p - 1] + 1);       // strictly increasing
-    for (int p = world - 1; p >= 0; --p) b[p] = std::min(b[p], b[p + 1] - 1);
+    // b[0] = 0 and b[world] = n stay fixed: leave room on the right first (a hub in the last rows puts several
+    // cuts at n), then make the cuts strictly increasing (world <= n makes both satisfiable)
+    for (int p = world - 1; p >= 1; --p) b[p] = std::min(b[p], n - (int64_t)(world - p));
+    for (int p = 1; p < world; ++p) b[p] = std::max(b[p], b[p - 1] + 1);
     return b;
 }
 

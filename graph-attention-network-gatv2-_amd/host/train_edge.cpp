@@ -239,13 +239,25 @@ void check(int rc, const char* what) {
     }
 }
 
-int run(const Options& o, const RankEnv& env) {
-    size_t free_before = 0, total_mem = 0;
-    if (gat_mem_info(&free_before, &total_mem) != 0)       // like the reference: report and go on (E:1189-1192)
+// E:929-933.  The reference prints this block BEFORE it looks at argv (E:943), so its argument-error exits
+// still show it; main() therefore calls it ahead of parse_args.  With --ranks P > 1 the parent must not touch
+// the HIP runtime before forking, so there rank 0 prints it at the start of run() instead.
+size_t g_free_before = 0;
+bool g_tracker_printed = false;
+void print_memory_tracker_before() {
+    size_t total_mem = 0;
+    if (gat_mem_info(&g_free_before, &total_mem) != 0)     // like the reference: report and go on (E:1189-1192)
         std::fprintf(stderr, "Error launching gat_mem_info: %s\n", gat_last_error());
     std::printf("\n[Memory Tracker] Before allocation:\n");
     std::printf("  Total GPU memory: %.2f MB\n", total_mem / (1024.0 * 1024.0));
-    std::printf("  Free GPU memory : %.2f MB\n", free_before / (1024.0 * 1024.0));
+    std::printf("  Free GPU memory : %.2f MB\n", g_free_before / (1024.0 * 1024.0));
+    g_tracker_printed = true;
+}
+
+int run(const Options& o, const RankEnv& env) {
+    if (!g_tracker_printed) print_memory_tracker_before();
+    const size_t free_before = g_free_before;
+    size_t total_mem = 0;
 
     const int L = o.layers;
     std::cout << "Configuration:\n"
@@ -415,6 +427,10 @@ int run(const Options& o, const RankEnv& env) {
 }  // namespace
 
 int main(int argc, char** argv) {
+    bool multi = false;                                    // --ranks P > 1: see print_memory_tracker_before
+    for (int i = 1; i + 1 < argc; ++i)
+        if (std::string(argv[i]) == "--ranks" && std::atoi(argv[i + 1]) > 1) multi = true;
+    if (!multi) print_memory_tracker_before();
     Options o = parse_args(argc, argv);
     if (!o.seed_given) { o.seed = (uint64_t)time(nullptr); o.seed_given = true; }     // E:1305; one seed for all ranks
     if (o.ranks == 1) return run(o, RankEnv{});

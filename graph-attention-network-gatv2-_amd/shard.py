@@ -81,10 +81,12 @@ def edge_balanced_bounds(row_ptr: np.ndarray, world: int) -> np.ndarray:
     targets = (np.arange(1, world, dtype=np.float64) * e / world)
     cuts = np.searchsorted(row_ptr, targets, side="left").astype(np.int64)
     b = np.concatenate([[0], cuts, [n]])
-    for p in range(1, world + 1):                       # strictly increasing
+    # b[0] = 0 and b[world] = n stay fixed.  First leave room on the right (a hub in the last rows puts
+    # several cuts at n), then make the cuts strictly increasing; world <= n makes both satisfiable.
+    for p in range(world - 1, 0, -1):
+        b[p] = min(b[p], n - (world - p))
+    for p in range(1, world):
         b[p] = max(b[p], b[p - 1] + 1)
-    for p in range(world - 1, -1, -1):
-        b[p] = min(b[p], b[p + 1] - 1)
     return b
 
 
@@ -181,6 +183,7 @@ class ShardedGat:
         # staging buffer of the end-of-step all-reduce: packed gradients + [loss, correct lo, correct hi]
         self._packed = alloc(ctx.n_params + 3)
         self.grads = self._packed[: ctx.n_params]
+        self._alloc, self._prev = alloc, None
         # layer 0 of a context with replicated input needs no exchange (see module docstring)
         self.exchange = [bool(ctx.layer_exchange(l)) if hasattr(ctx, "layer_exchange") else True
                          for l in range(self.L)]
@@ -211,23 +214,38 @@ class ShardedGat:
         self.comm.all_reduce_(s)
         return float(s[0]), int(round(float(s[1])))
 
+    def _set_aside(self):
+        """The context's gradient buffer accumulates until zero_grad (E:1631-1633) and already holds
+        REDUCED sums of earlier steps: set them aside and run this step into a zeroed buffer, so that
+        the all-reduce sums only this step's per-shard contributions (else earlier steps would be
+        multiplied by the world size on every further step)."""
+        n = self.grads.numel()
+        if self._prev is None:
+            self._prev = self._alloc(n)
+        self.ctx.grads_export(self._prev.data_ptr(), n)
+        self.ctx.zero_grad()
+
     def backward(self):
+        self._set_aside()
         self._backward_phases()
         # W/a/Wo gradients: one packed buffer (tens of KB: latency-bound, a single all-reduce)
         self.ctx.grads_export(self.grads.data_ptr(), self.grads.numel())
         self.comm.all_reduce_(self.grads)
+        self.grads.add_(self._prev)
         self.ctx.grads_import(self.grads.data_ptr(), self.grads.numel())
 
     def step(self):
         """forward + backward with no host synchronisation until the end: loss and #correct ride in
         the tail of the packed-gradient all-reduce.  -> (global loss sum, global #correct)"""
         n = self.grads.numel()
+        self._set_aside()
         self._forward_phases()
         self.ctx.head_forward(want_loss=False)
         self._backward_phases()
         self.ctx.grads_export(self._packed.data_ptr(), n)
         self.ctx.result_export(self._packed.data_ptr() + 4 * n)
         self.comm.all_reduce_(self._packed)
+        self.grads.add_(self._prev)
         self.ctx.grads_import(self._packed.data_ptr(), n)
         tail = self._packed[n:].cpu()
         return float(tail[0]), int(round(float(tail[1]) + 4096.0 * float(tail[2])))

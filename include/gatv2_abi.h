@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAT_ABI_VERSION 2
+#define GAT_ABI_VERSION 3
 
 enum {
     GAT_OK = 0,
@@ -77,6 +77,9 @@ int gat_mem_info(size_t* free_bytes, size_t* total_bytes);   /* cudaMemGetInfo, 
  * table_row0 == 0.  Destination-range shard: the context owns rows
  * [table_row0, table_row0+n_rows) of an n_table-row source table and col_idx holds table row
  * ids (see INTEGRATION.md "sharding"); host arrays are copied. */
+/* Limits: n_edges, n_rows and n_table must each fit int32 (the reference's CSR is int32 too, E:1045-1046; the
+ * one-time source-major index is built with a 32-bit-count radix sort) — larger graphs are refused with
+ * GAT_E_UNSUPPORTED, never truncated.  Offsets INTO tensors are 64-bit everywhere. */
 int gat_set_graph(gat_ctx* ctx, const int32_t* row_ptr, const int32_t* col_idx, int64_t n_rows,
                   int64_t n_edges, int64_t n_table, int64_t table_row0);
 int gat_set_features(gat_ctx* ctx, const float* x, int64_t n_rows, int32_t in_dim);   /* [n_rows][F0] */
@@ -187,7 +190,11 @@ enum {
     GAT_TAP_MAX = 8,        /* [H][N]                d_max_attn_score (E:356) */
     GAT_TAP_SUM = 9,        /* [H][N]                d_sum_score_exp (E:357) */
     GAT_TAP_PL = 10,        /* [n_table][H*D]        W_left·x  (the product's own intermediate) */
-    GAT_TAP_PR = 11         /* [N][H*D]              W_right·x */
+    GAT_TAP_PR = 11,        /* [N][H*D]              W_right·x */
+    GAT_TAP_SCORE = 12,     /* [H][E]                attn_score[l] (E:323), keep_taps */
+    GAT_TAP_GALPHA = 13,    /* [H][E]                grad_attn_coeff (E:646), keep_taps */
+    GAT_TAP_GX = 14         /* [N][F_l], l >= 1      input_gradients[l-1] as compute_features_input_gradients leaves
+                                                      it (E:868-869), BEFORE the LReLU'(h_pre_{l-1}) factor of E:888-892 */
 };
 int gat_tap(gat_ctx* ctx, int tensor, int32_t layer, void* host_dst, int64_t count);
 
@@ -224,6 +231,12 @@ int gat_kernel_stats_reset(gat_ctx* ctx);
 const char* gat_kernel_name(int k);
 /* Algorithmic HBM bytes of one forward+backward step on this context's shard. */
 int gat_algorithmic_bytes(gat_ctx* ctx, double* bytes_step, double* bytes_per_kernel /* [GAT_K_COUNT] or NULL */);
+/* The same figure from the shape alone (host arithmetic, no device, no context): SURVEY §8d's formula with
+ * b = 4 (GAT_DTYPE_F32) or 2 (GAT_DTYPE_BF16) bytes on every float term.  n_table / replicated_input describe a
+ * destination-range shard (single GPU: n_table = n_rows, replicated_input = 0).  Only cfg->num_layers, heads,
+ * outdims, in_dim, num_classes and storage_dtype are read. */
+int gat_algorithmic_bytes_shape(const gat_config* cfg, int64_t n_rows, int64_t n_edges, int64_t n_table,
+                                int32_t replicated_input, double* bytes_step, double* bytes_per_kernel);
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,8 @@
 // PARITY PINNING: the reference ships no tests, golden vectors or datasets, and it is
 // CUDA source (no nvcc here), so it can be neither run nor compiled in this image.
 // The restatement is therefore pinned by (1) torch-autograd fp64 agreement of the whole
-// forward/backward (tests/test_oracle_autograd.py), (2) finite differences, (3) the
-// invariants of tests/test_oracle_invariants.py.  With respect to the reference's own
+// forward/backward (tests/test_oracle.py::test_oracle_matches_autograd), (2) finite differences
+// (test_finite_difference), (3) the invariants checked in tests/test_oracle.py.  With respect to the reference's own
 // fixtures this is "parity unpinned" (there are none to pin against).
 //
 // Modes:
@@ -91,6 +91,37 @@ void orc_edge_score(const float* X, const int* col_idx, const int* dst, const fl
             ev += ah[k] * lrelu(acc, slope);
         }
         score[(size_t)h * E + e] = ev;
+    }
+}
+
+// ---- kink probe (not a reference kernel) ---------------------------------------------------
+// The pre-activation s[e][h][k] = W[h,k,0:F].x_src + W[h,k,F:2F].x_dst exactly as the reference's
+// threads form it, in the TWO float orders the reference itself uses: interleaved = 0 is the order of
+// a2 / a9 (left half then right half into one accumulator, E:303-316, E:746-752), interleaved = 1 the
+// order of a10 (left and right term alternating, E:848-853).  LeakyReLU' is discontinuous at s = 0
+// (E:774, 855), so a parity test needs to know on which side each evaluation landed; the tests compare
+// these signs with the signs the HIP path took and account for the (rare) differences explicitly.
+void orc_presum(const float* X, const int* src, const int* dst, const float* W, float* s_out,
+                int F, int D, int H, int E, int interleaved) {
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < E; ++e) {
+        const float* xs = X + (size_t)src[e] * F;
+        const float* xd = X + (size_t)dst[e] * F;
+        for (int h = 0; h < H; ++h)
+            for (int k = 0; k < D; ++k) {
+                const float* wl = W + ((size_t)h * D + k) * (2 * F);
+                float acc = 0.f;
+                if (!interleaved) {
+                    for (int d = 0; d < F; ++d) acc += wl[d] * xs[d];
+                    for (int d = 0; d < F; ++d) acc += wl[F + d] * xd[d];
+                } else {
+                    for (int d = 0; d < F; ++d) {
+                        acc += wl[d] * xs[d];
+                        acc += wl[d + F] * xd[d];
+                    }
+                }
+                s_out[((size_t)e * H + h) * D + k] = acc;
+            }
     }
 }
 

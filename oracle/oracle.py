@@ -7,7 +7,7 @@ epoch loop (GATv2_edge_based.cu, cited E:<line>): forward E:1374-1460, backward 
 Allowed importers: tests/, ``__graft_entry__.smoke()``, ``bench.py``'s cpu_baseline leg.
 With respect to the reference's own fixtures the parity is *unpinned* (the reference has no
 tests, goldens or datasets); the restatement is pinned by autograd/finite differences instead
-(tests/test_oracle_autograd.py).
+(tests/test_oracle.py).
 """
 from __future__ import annotations
 
@@ -27,11 +27,28 @@ i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 
 def build(force: bool = False) -> str:
-    so = os.path.join(_HERE, "libgatv2_oracle.so")
+    """GAT_ORACLE_NATIVE=1 (set by bench.py's cpu_baseline leg before the first load): the -O3 -march=native
+    build of BASELINE.md §3, compiled on the machine that times it; falls back to the portable build if the
+    compiler is missing there."""
+    native = os.environ.get("GAT_ORACLE_NATIVE") == "1"
     src = os.path.join(_HERE, "gatv2_oracle.cpp")
+    if native:
+        so = os.path.join(_HERE, "libgatv2_oracle_native.so")
+        try:
+            # always rebuilt: -march=native must mean THIS machine, not the one a stale file came from
+            subprocess.check_call(["make", "-B", "-C", _HERE, "libgatv2_oracle_native.so"], stdout=subprocess.DEVNULL)
+            return so
+        except (OSError, subprocess.CalledProcessError):
+            pass
+    so = os.path.join(_HERE, "libgatv2_oracle.so")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "libgatv2_oracle.so"], stdout=subprocess.DEVNULL)
     return so
+
+
+def build_flags() -> str:
+    return ("-O3 -march=native -ffp-contract=fast -fopenmp" if _LIB is not None and "native" in str(_LIB._name)
+            else "-O2 -mavx2 -mfma -ffp-contract=fast -fopenmp")
 
 
 def lib() -> C.CDLL:
@@ -44,6 +61,7 @@ def lib() -> C.CDLL:
         "orc_num_threads": ([], i),
         "orc_csr_to_coo": ([i32p, i32p, i32p, i32p, i], None),
         "orc_edge_score": ([f32p, i32p, i32p, f32p, f32p, f32p, i, i, i, i, i, f], None),
+        "orc_presum": ([f32p, i32p, i32p, f32p, f32p, i, i, i, i, i], None),
         "orc_max_sum": ([i32p, f32p, i, i, i, f32p, f32p], None),
         "orc_attn_coeff": ([i32p, f32p, f32p, f32p, f32p, i, i, i], None),
         "orc_aggregate": ([i32p, i32p, f32p, f32p, f32p, f32p, i, i, i, i, i], None),
@@ -230,6 +248,28 @@ def step(cfg: Config, row_ptr, col_idx, labels, X0, W, a, Wo, *, flat_lrelu_inde
         Lb.orc_preact_gradient(N, NEG_SLOPE, F, taps["hpre"][l - 1].reshape(-1), g[l - 1])  # E:1546
     r.gradW, r.grada, r.gradWo = gradW, grada, gradWo
     return r
+
+
+def presum_signs(cfg: Config, row_ptr, col_idx, X0, W, ref: "StepResult"):
+    """Per layer the sign decisions (s > 0) of the literal restatement, in both float orders the reference
+    uses: -> (pos_lr[l], pos_il[l]) bool arrays [E][H][D]; see orc_presum.  Test infrastructure for the
+    LeakyReLU-kink bookkeeping of tests/parity.py."""
+    Lb = lib()
+    E = len(col_idx)
+    src = np.ascontiguousarray(col_idx, np.int32)
+    dst = np.ascontiguousarray(ref.dst, np.int32)
+    W = np.ascontiguousarray(W, np.float32)
+    out_lr, out_il = [], []
+    for l in range(cfg.L):
+        H, D, F = cfg.heads[l], cfg.outdims[l], cfg.in_dims[l]
+        Xl = np.ascontiguousarray(ref.taps["H"][l - 1] if l > 0 else X0, np.float32).reshape(-1)
+        Wl = W[cfg.w_offsets[l]:cfg.w_offsets[l + 1]]
+        s = np.empty(E * H * D, np.float32)
+        Lb.orc_presum(Xl, src, dst, Wl, s, F, D, H, E, 0)
+        out_lr.append((s > 0).reshape(E, H, D))
+        Lb.orc_presum(Xl, src, dst, Wl, s, F, D, H, E, 1)
+        out_il.append((s > 0).reshape(E, H, D))
+    return out_lr, out_il
 
 
 def step_restructured(cfg: Config, row_ptr, col_idx, labels, X0, W, a, Wo):

@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+TESTS = os.path.dirname(os.path.abspath(__file__))
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)
+
 import __graft_entry__ as entry  # noqa: E402
 
 
@@ -45,13 +49,14 @@ def small_graph(rng, n, e, hub=None, empty=(), n_src=None):
     return row_ptr, col
 
 
-def grad_close(got, want, tol=1e-3, frac=0.005):
-    """Gradient comparison that tolerates LeakyReLU-kink hits: LReLU'(s) is discontinuous at s = 0
-    (1 vs 0.01, E:774/855), so when some |s| is ~1e-8 two correct fp32 evaluation orders may land on
-    different sides and a handful of gradient entries move by O(1e-3) of the tensor's scale.  Accept
-    if all but `frac` of the entries agree to `tol` of max|want| and the relative L2 error is small."""
-    got = np.asarray(got, np.float64).ravel(); want = np.asarray(want, np.float64).ravel()
-    scale = max(1e-12, np.abs(want).max())
-    err = np.abs(got - want)
-    l2 = np.linalg.norm(err) / max(1e-12, np.linalg.norm(want))
-    return bool((err > tol * scale).mean() <= frac and l2 < max(10 * tol, 5e-3)), (float(err.max() / scale), float(l2))
+@pytest.fixture(autouse=True)
+def _parity_test_name(request):
+    """Achieved errors are recorded per test (tests/parity.py) and written out at the end of the session."""
+    import parity
+    parity.set_test(request.node.nodeid)
+    yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import parity
+    parity.flush()

@@ -1,0 +1,163 @@
+"""Parity bookkeeping shared by the GPU tests: the contract's tolerances, the record of ACHIEVED errors, and the
+explicit treatment of LeakyReLU kinks.
+
+Tolerances (BASELINE.json north_star): CSR->COO bit-exact; attention / h_pre / y / loss within 1e-4;
+every gradient tensor within 1e-4 of its max-abs.  No outlier fractions, no L2 budgets.
+
+LeakyReLU' is discontinuous at 0 (E:599, 774, 855, 890).  Where a pre-activation is within fp32 round-off of 0
+the HIP path (s = PL[src] + PR[dst], fp32 MFMA projections) and the literal oracle (one accumulator over 2F
+terms) may take different sides; the gradients then differ by a finite jump that has nothing to do with
+accuracy.  Instead of loosening the bar, the tests
+  1. read the HIP path's own sign decisions from its taps (PL, PR, h_pre) and the oracle's from orc_presum /
+     its h_pre,
+  2. list the entries where they differ ("flips": typically 0, a handful at most — asserted and recorded),
+  3. evaluate in fp64 (tests/ref64.py) what those flips do to every gradient tensor, and
+  4. compare the HIP result with  oracle + that correction  at the full 1e-4 bar.
+With no flips the comparison is simply HIP vs oracle at 1e-4.
+
+Every comparison is recorded (max error relative to the tensor's scale, tolerance, flips) and written to
+gpurun_out/parity_errors.json at the end of the session (copied to profiles/ for the record).
+"""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TOL = 1e-4        # forward tensors and loss (north_star)
+GTOL = 1e-4       # gradients, relative to the tensor's max-abs
+MAX_FLIPS = 64    # more than this in a small test means something other than round-off is going on
+
+_LOG = {}
+_CURRENT = [os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]]      # subprocess snippets inherit the name
+
+
+def set_test(name):
+    _CURRENT[0] = name
+
+
+def record(name, err, tol, **extra):
+    ent = {"err": float(err), "tol": float(tol)}
+    ent.update(extra)
+    _LOG.setdefault(_CURRENT[0], {})[name] = ent
+
+
+def flush():
+    if not _LOG:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "parity_errors.json")
+        old = {}
+        if os.path.exists(path):
+            try:
+                old = json.load(open(path))
+            except Exception:      # noqa: BLE001 - a truncated file from a killed run is simply replaced
+                old = {}
+        old.update(_LOG)
+        with open(path, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def rel_err(got, want, floor=1e-12):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    if got.size == 0:
+        return 0.0
+    return float(np.abs(got - want).max() / max(floor, np.abs(want).max()))
+
+
+def check_rel(name, got, want, tol=GTOL, floor=1e-12, **extra):
+    """max|got - want| <= tol * max|want|  (recorded, then asserted)."""
+    err = rel_err(got, want, floor)
+    record(name, err, tol, **extra)
+    assert err <= tol, (name, err, tol)
+    return err
+
+
+def check_abs(name, got, want, tol=TOL):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    err = float(np.abs(got - want).max()) if got.size else 0.0
+    record(name, err, tol, kind="abs")
+    assert err <= tol, (name, err, tol)
+    return err
+
+
+class Flips:
+    """Sign decisions of both sides and where they differ."""
+
+    def __init__(self, cfg, gpu_s, gpu_h, orc_lr, orc_il, orc_h):
+        self.cfg = cfg
+        self.gpu_s, self.gpu_h = gpu_s, gpu_h
+        self.orc_lr, self.orc_il, self.orc_h = orc_lr, orc_il, orc_h
+        self.n_s_params = [int((g != o).sum()) for g, o in zip(gpu_s, orc_lr)]
+        self.n_s_gx = [int((g != o).sum()) for g, o in zip(gpu_s, orc_il)]
+        self.n_h = [int((g != o).sum()) for g, o in zip(gpu_h, orc_h)]
+
+    @property
+    def total(self):
+        return sum(self.n_s_params) + sum(self.n_s_gx) + sum(self.n_h)
+
+    def summary(self):
+        return {"s_params": self.n_s_params, "s_gx": self.n_s_gx, "h_pre": self.n_h}
+
+
+def find_flips(orc, cfg, row_ptr, col_idx, x, W, ref, ctx, A):
+    """ctx: a GatContext created with keep_taps=True after forward+backward; ref: orc.step() of the same inputs."""
+    src = np.asarray(col_idx, np.int64)
+    dst = np.asarray(ref.dst, np.int64)
+    gpu_s, gpu_h = [], []
+    for l in range(cfg.L):
+        H, D = cfg.heads[l], cfg.outdims[l]
+        PL = ctx.tap(A.TAP_PL, l); PR = ctx.tap(A.TAP_PR, l)
+        s = (PL[src] + PR[dst]).astype(np.float32)                       # the kernels' own fp32 add (v + pr)
+        gpu_s.append((s > 0).reshape(len(src), H, D))
+        gpu_h.append(ctx.tap(A.TAP_HPRE, l) > 0)
+    orc_lr, orc_il = orc.presum_signs(cfg, row_ptr, col_idx, x, W, ref)
+    orc_h = [ref.taps["hpre"][l] > 0 for l in range(cfg.L)]
+    return Flips(cfg, gpu_s, gpu_h, orc_lr, orc_il, orc_h)
+
+
+def expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, max_flips=MAX_FLIPS):
+    """-> dict(g, galpha, ge, gx (lists per layer, reference layouts), gradW, grada, gradWo): the oracle's values,
+    plus — only where sign decisions differ — the fp64-evaluated effect of the HIP path's decisions."""
+    exp = dict(g=[t for t in ref.taps["g"]], galpha=list(ref.taps["galpha"]), ge=list(ref.taps["ge"]),
+               gx=list(ref.taps["gx"]), gradW=ref.gradW, grada=ref.grada, gradWo=ref.gradWo)
+    record("kink_flips", flips.total, max_flips, **flips.summary())
+    assert flips.total <= max_flips, ("too many LeakyReLU sign differences for round-off", flips.summary())
+    if flips.total == 0:
+        return exp
+    import ref64
+    fw = ref64.forward(cfg, row_ptr, col_idx, labels, x, W, a, Wo)
+    b_gpu = ref64.backward(cfg, fw, flips.gpu_s, flips.gpu_s, flips.gpu_h)
+    b_orc = ref64.backward(cfg, fw, flips.orc_lr, flips.orc_il, flips.orc_h)
+    out = {}
+    for k in ("gradW", "grada", "gradWo"):
+        out[k] = np.asarray(exp[k], np.float64) + (b_gpu[k] - b_orc[k])
+    for k in ("g", "galpha", "ge", "gx"):
+        out[k] = [None if e is None else np.asarray(e, np.float64) + (bg - bo).reshape(np.shape(e))
+                  for e, bg, bo in zip(exp[k], b_gpu[k], b_orc[k])]
+    return out
+
+
+def check_context_gradients(orc, A, cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, ctx, taps=False, prefix="",
+                            max_flips=MAX_FLIPS):
+    """The whole gradient comparison of one context after forward+backward against the oracle result `ref`, at
+    GTOL with the kink bookkeeping above.  taps=True also compares g, galpha, ge and gx per layer (needs a
+    context created with keep_taps=True).  -> Flips"""
+    flips = find_flips(orc, cfg, row_ptr, col_idx, x, W, ref, ctx, A)
+    exp = expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, max_flips)
+    if taps:
+        for l in range(cfg.L - 1, -1, -1):
+            check_rel(f"{prefix}g[{l}]", ctx.tap(A.TAP_G, l), exp["g"][l])
+            check_rel(f"{prefix}galpha[{l}]", ctx.tap(A.TAP_GALPHA, l), exp["galpha"][l])
+            check_rel(f"{prefix}ge[{l}]", ctx.tap(A.TAP_GE, l), exp["ge"][l])
+            if l > 0:
+                check_rel(f"{prefix}gx[{l}]", ctx.tap(A.TAP_GX, l), exp["gx"][l])
+    check_rel(f"{prefix}gradWo", ctx.grads_get(A.PARAM_WO), exp["gradWo"])
+    check_rel(f"{prefix}grada", ctx.grads_get(A.PARAM_A), exp["grada"])
+    check_rel(f"{prefix}gradW", ctx.grads_get(A.PARAM_W), exp["gradW"])
+    return flips

@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 40
     for n in names:
         assert hasattr(lib, n), f"{n} declared in gatv2_abi.h but not exported"
-    assert lib.gat_abi_version() == 2
+    assert lib.gat_abi_version() == 3
 
 
 def test_code_object_is_gfx950_only(pkg):
@@ -44,3 +44,30 @@ def test_missing_library_fails_loudly(pkg, monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("loading a missing HIP library must raise")
+
+
+def test_algorithmic_bytes_match_the_survey_worked_values(pkg):
+    """SURVEY 8d's worked values of bytes_step (the figure every roofline fraction is quoted against), evaluated
+    by the library's own host-side function — no GPU involved.  fp32 unless stated; config 5 is bf16 storage
+    (b = 2 on every float term), which round 1 mis-priced at b = 4 (VERDICT r1 weak #4)."""
+    A = pkg.abi
+    cases = [   # heads, outdims, F0, C, N, E, dtype, GB
+        ((8, 1), (8, 8), 1433, 7, 2708, 5429, "f32", 0.049),                     # (1) Cora-shape, P-parity preset
+        ((8, 8), (8, 8), 500, 3, 19717, 44338, "f32", 0.284),                    # (2) Pubmed-shape
+        ((8, 8, 8), (8, 8, 8), 128, 40, 169343, 1166243, "f32", 5.02),           # (3) Arxiv-shape, 3 layers
+        ((8, 8), (8, 8), 100, 47, 2450000, 61900000, "f32", 123.8),              # (4) Products-shape, P-bench (headline)
+        ((8, 1), (8, 8), 100, 47, 2450000, 61900000, "f32", 72.7),               #     P-parity
+        ((4, 4), (8, 8), 128, 47, 10_000_000, 250_000_000, "bf16", 137.8),       # (5) 10 M / 250 M, 4 heads, bf16
+    ]
+    for heads, outdims, f, c, n, e, dt, gb in cases:
+        tot, per = A.algorithmic_bytes_shape(heads, outdims, f, c, n, e, dtype=dt)
+        assert abs(tot / 1e9 - gb) <= 0.006 * gb + 0.0005, (heads, dt, tot / 1e9, gb)
+        assert abs(sum(per.values()) - tot) < 1e-3
+    # per-edge figure of the headline: 2,000 B/edge (SURVEY 8d)
+    tot, _ = A.algorithmic_bytes_shape((8, 8), (8, 8), 100, 47, 2450000, 61900000)
+    assert abs(tot / 61900000 - 2000) < 1.0
+    # bf16 halves every float term of the fp32 figure (indices stay 4 bytes)
+    f32, _ = A.algorithmic_bytes_shape((4, 4), (8, 8), 128, 47, 10_000_000, 250_000_000)
+    bf, _ = A.algorithmic_bytes_shape((4, 4), (8, 8), 128, 47, 10_000_000, 250_000_000, dtype="bf16")
+    idx = 2 * 2 * (4 * (10_000_000 + 1) + 4 * 250_000_000) + 2 * 4 * 10_000_000 * (8 + 2 * 47 + 2)
+    assert abs((f32 - idx) / 2 + idx - bf) < 1.0

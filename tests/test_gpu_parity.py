@@ -1,17 +1,17 @@
 """GPU parity: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same
-seeded inputs.  Tolerances (north_star): CSR->COO bit-exact; attention / h_pre / y / loss 1e-4;
-gradients 1e-4 (fp32 order effects: 1e-3) of the tensor's max-abs."""
+seeded inputs.  Tolerances (north_star, SURVEY 8c): CSR->COO bit-exact; attention / h_pre / y / loss 1e-4;
+every gradient tensor within 1e-4 of its max-abs, LeakyReLU kinks accounted for entry by entry
+(tests/parity.py); achieved errors are recorded in gpurun_out/parity_errors.json."""
 import os
 
 import numpy as np
 import pytest
 
-from conftest import grad_close, small_graph
+import parity
+from conftest import small_graph
+from parity import TOL, GTOL, check_abs, check_rel
 
 pytestmark = pytest.mark.gpu
-
-TOL = 1e-4
-GTOL = 1e-3
 
 
 def _inputs(orc, seed, n, e, heads, outdims, f, c, hub=None, empty=()):
@@ -40,11 +40,6 @@ def _relerr(got, ref):
     return float(np.abs(got - ref).max() / max(1e-6, np.abs(ref).max()))
 
 
-def _gclose(got, ref, what=""):
-    ok, info = grad_close(got, ref, GTOL)
-    assert ok, (what, info)
-
-
 CASES = [
     # heads, outdims, F, N, E, hub(row,deg), empty rows        -- E never a multiple of 64/256 (Q3)
     ((8, 8), (8, 8), 100, 300, 4001, (5, 700), (0, 17, 299)),   # the bench preset, fast path HD=64
@@ -68,20 +63,17 @@ def test_step_parity(pkg, orc, heads, outdims, f, n, e, hub, empty):
         assert np.array_equal(ctx.tap(A.TAP_SRC), ref.src)
         assert np.array_equal(ctx.tap(A.TAP_DST), ref.dst)
         for l in range(cfg.L):
-            assert np.abs(ctx.tap(A.TAP_ALPHA, l) - ref.taps["alpha"][l]).max() < TOL, f"alpha l={l}"
-            assert _relerr(ctx.tap(A.TAP_HPRE, l), ref.taps["hpre"][l]) < TOL, f"hpre l={l}"
-            assert _relerr(ctx.tap(A.TAP_HOUT, l), ref.taps["H"][l]) < TOL, f"H l={l}"
-            assert _relerr(ctx.tap(A.TAP_SUM, l), ref.taps["sum"][l]) < TOL
+            check_rel(f"score[{l}]", ctx.tap(A.TAP_SCORE, l), ref.taps["score"][l], TOL)          # a2
+            check_abs(f"alpha[{l}]", ctx.tap(A.TAP_ALPHA, l), ref.taps["alpha"][l])               # a4
+            check_rel(f"hpre[{l}]", ctx.tap(A.TAP_HPRE, l), ref.taps["hpre"][l], TOL)             # a5
+            check_rel(f"H[{l}]", ctx.tap(A.TAP_HOUT, l), ref.taps["H"][l], TOL)                   # a6
+            check_rel(f"sum[{l}]", ctx.tap(A.TAP_SUM, l), ref.taps["sum"][l], TOL)                # a3
             assert np.allclose(ctx.tap(A.TAP_MAX, l), ref.taps["max"][l], rtol=1e-5, atol=1e-5)
-        assert np.abs(ctx.tap(A.TAP_Y) - ref.y).max() < TOL
-        assert abs(loss - ref.loss_sum_f64) / n < TOL
+        check_abs("y", ctx.tap(A.TAP_Y), ref.y)
+        check_abs("loss/N", loss / n, ref.loss_sum_f64 / n)
         assert correct == ref.n_correct
-        for l in range(cfg.L - 1, -1, -1):
-            _gclose(ctx.tap(A.TAP_G, l), ref.taps["g"][l], f"g l={l}")
-            _gclose(ctx.tap(A.TAP_GE, l), ref.taps["ge"][l], f"ge l={l}")
-        _gclose(ctx.grads_get(A.PARAM_WO), ref.gradWo, "gradWo")
-        _gclose(ctx.grads_get(A.PARAM_A), ref.grada, "grada")
-        _gclose(ctx.grads_get(A.PARAM_W), ref.gradW, "gradW")
+        # a7-a11 + parameter gradients at 1e-4, kinks accounted for
+        parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx, taps=True)
     finally:
         ctx.close()
 
@@ -93,8 +85,12 @@ def test_flat_lrelu_index_mode(pkg, orc):
     ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo, flat_lrelu_index=True)
     ctx, _, _ = _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo, flat_lrelu_index=True)
     try:
-        _gclose(ctx.grads_get(A.PARAM_W), ref.gradW, "gradW")
-        _gclose(ctx.grads_get(A.PARAM_A), ref.grada, "grada")
+        # the flat index changes which h_pre entry each LReLU' reads (E:598), so the kink bookkeeping of
+        # parity.py does not apply: this seed has no sign difference (asserted), plain 1e-4
+        fl = parity.find_flips(orc, cfg, rp, ci, x, W, ref, ctx, A)
+        assert fl.total == 0, fl.summary()
+        check_rel("gradW", ctx.grads_get(A.PARAM_W), ref.gradW)
+        check_rel("grada", ctx.grads_get(A.PARAM_A), ref.grada)
     finally:
         ctx.close()
 
@@ -167,8 +163,16 @@ def test_op_level_entry_points(pkg, orc):
     rc = lib.gat_op_layer_backward(p(d_rp), p(d_ci), p(d_x), p(Wl), p(al), p(d_alpha), p(d_hpre), p(d_g), p(gw), p(ga),
                                    None, None, n, e, f, H, D, C.c_float(0.01), None)
     assert rc == 0, lib.gat_last_error()
-    _gclose(gw.cpu().numpy(), ref.gradW[cfg.w_offsets[0]:cfg.w_offsets[1]], "op gradW")
-    _gclose(ga.cpu().numpy(), ref.grada[cfg.a_offsets[0]:cfg.a_offsets[1]], "op grada")
+    # the op's sign decisions are those of a context on the same inputs (same kernels): take the kink-corrected
+    # expectation from one
+    ctx, _, _ = _run_gpu(pkg, cfg, rp, ci, lab, x, W, a, Wo)
+    try:
+        fl = parity.find_flips(orc, cfg, rp, ci, x, W, ref, ctx, A)
+        exp = parity.expected_gradients(cfg, rp, ci, lab, x, W, a, Wo, ref, fl)
+    finally:
+        ctx.close()
+    check_rel("op gradW", gw.cpu().numpy(), exp["gradW"][cfg.w_offsets[0]:cfg.w_offsets[1]])
+    check_rel("op grada", ga.cpu().numpy(), exp["grada"][cfg.a_offsets[0]:cfg.a_offsets[1]])
 
 
 def test_error_paths(pkg):
@@ -206,10 +210,37 @@ def test_degenerate_graphs(pkg, orc):
         try:
             assert np.isfinite(loss) and abs(loss - ref.loss_sum_f64) / n < TOL and correct == ref.n_correct
             assert _relerr(ctx.tap(A.TAP_HPRE, 1), ref.taps["hpre"][1]) < TOL or np.abs(ref.taps["hpre"][1]).max() == 0
-            _gclose(ctx.grads_get(A.PARAM_W), ref.gradW, "gradW")
-            _gclose(ctx.grads_get(A.PARAM_WO), ref.gradWo, "gradWo")
+            parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx, prefix=f"n{n}:")
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("heads,outdims", [((8, 8), (8, 8)), ((4, 2), (8, 4)), ((2, 2), (8, 8))])
+def test_training_path_with_empty_first_row_and_without_edges(pkg, orc, heads, outdims):
+    """the packed training kernels (keep_taps=0) prefetch a chunk's edge indices before their loop; for
+    an item with beg == end == 0 (row 0 without in-edges, or a shard without edges) the clamped index was -1.
+    Row 0 empty + trailing empty rows, and E == 0, through forward+backward of the training path."""
+    A = pkg.abi
+    rng = np.random.default_rng(12)
+    n = 150
+    rp, ci = small_graph(rng, n, 1900, hub=(40, 300), empty=(0, 1, 2, n - 1))
+    assert rp[1] == 0 and rp[3] == 0
+    for rp_, ci_ in ((rp, ci), (np.zeros(n + 1, np.int32), np.zeros(0, np.int32))):
+        x = rng.standard_normal((n, 9)).astype(np.float32)
+        lab = rng.integers(0, 4, n).astype(np.int32); lab[0] = 3
+        cfg = orc.Config(list(heads), list(outdims), 9, 4)
+        W, a, Wo = orc.xavier_params(cfg, 9)
+        ref = orc.step(cfg, rp_, ci_, lab, x, W, a, Wo)
+        with pkg.GatContext(cfg.heads, cfg.outdims, 9, 4) as ctx:
+            ctx.set_graph(rp_, ci_); ctx.set_features(x); ctx.set_labels(lab)
+            ctx.params_set(A.PARAM_W, W); ctx.params_set(A.PARAM_A, a); ctx.params_set(A.PARAM_WO, Wo)
+            ctx.zero_grad()
+            loss, correct = ctx.step()
+            check_abs(f"E={len(ci_)} loss/N", loss / n, ref.loss_sum_f64 / n)
+            assert correct == ref.n_correct
+            hp = ctx.tap(A.TAP_HPRE, 0)
+            assert np.all(hp[0] == 0) and np.all(hp[n - 1] == 0)             # zero in-degree rows give exactly 0 (SURVEY 2.2)
+            parity.check_context_gradients(orc, A, cfg, rp_, ci_, lab, x, W, a, Wo, ref, ctx, prefix=f"E={len(ci_)} ")
 
 
 def test_wide_heads_generic_path(pkg, orc):
@@ -222,8 +253,7 @@ def test_wide_heads_generic_path(pkg, orc):
         assert abs(loss - ref.loss_sum_f64) / 60 < TOL and correct == ref.n_correct
         for l in range(3):
             assert np.abs(ctx.tap(A.TAP_ALPHA, l) - ref.taps["alpha"][l]).max() < TOL
-        _gclose(ctx.grads_get(A.PARAM_W), ref.gradW, "gradW")
-        _gclose(ctx.grads_get(A.PARAM_A), ref.grada, "grada")
+        parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx)
     finally:
         ctx.close()
 
@@ -240,7 +270,7 @@ def test_source_hub_both_gpl_sum_variants(pkg, orc, group, monkeypatch):
         sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
         sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
         import __graft_entry__ as entry
-        from conftest import grad_close
+        import parity
         pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
         rng = np.random.default_rng(17)
         n = 1100         # source 3 is in every row: 1100 slots = 3 chunks of the heavy-source path (kHeavySlots = 512)
@@ -258,10 +288,9 @@ def test_source_hub_both_gpl_sum_variants(pkg, orc, group, monkeypatch):
             for g, arr in enumerate((W, a, Wo)): ctx.params_set(g, arr)
             ctx.zero_grad(); loss, correct = ctx.forward(); ctx.backward()
             assert abs(loss - ref.loss_sum_f64) / n < 1e-4 and correct == ref.n_correct
-            for grp, want in ((A.PARAM_W, ref.gradW), (A.PARAM_A, ref.grada), (A.PARAM_WO, ref.gradWo)):
-                ok, info = grad_close(ctx.grads_get(grp), want, 1e-3)
-                assert ok, (heads, grp, info)
+            parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx)
             ctx.close()
+        parity.flush()
         print("OK")
     """)
     env = dict(os.environ, GAT_GPL_GROUP=group)
@@ -310,7 +339,6 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
     h = hd // d
     cfg, rp, ci, lab, x, W, a, Wo = _inputs(orc, 100 + hd + d, 120, 1000, (h, h), (d, d), 10, 4, hub=(6, 300), empty=(2,))
     ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
-    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
     for keep_taps in (False, True):
         ctx = pkg.GatContext(cfg.heads, cfg.outdims, cfg.in_dim0, cfg.num_classes, keep_taps=keep_taps)
         try:
@@ -324,9 +352,8 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
                 assert _relerr(ctx.tap(A.TAP_HPRE, l), ref.taps["hpre"][l]) < TOL
                 if keep_taps:
                     assert np.abs(ctx.tap(A.TAP_ALPHA, l) - ref.taps["alpha"][l]).max() < TOL
-            got = np.concatenate([ctx.grads_get(g) for g in (A.PARAM_W, A.PARAM_A, A.PARAM_WO)])
-            ok, info = grad_close(got, want, 1e-3)
-            assert ok, (keep_taps, info)
+            parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx, taps=keep_taps,
+                                           prefix=f"taps={int(keep_taps)}:")
         finally:
             ctx.close()
 
@@ -342,7 +369,8 @@ def test_ab_switches_stay_correct(pkg, orc, env):
         sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
         sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
         import __graft_entry__ as entry
-        from conftest import grad_close, small_graph
+        import parity
+        from conftest import small_graph
         pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
         rng = np.random.default_rng(5)
         rp, ci = small_graph(rng, 260, 2600, hub=(9, 700), empty=(0, 3))
@@ -358,10 +386,9 @@ def test_ab_switches_stay_correct(pkg, orc, env):
             ctx.zero_grad(); loss, correct = ctx.step()
             assert abs(loss - ref.loss_sum_f64) / 260 < 1e-4 and correct == ref.n_correct
             assert np.abs(ctx.tap(A.TAP_HPRE, 1) - ref.taps["hpre"][1]).max() < 1e-4 * max(1.0, np.abs(ref.taps["hpre"][1]).max())
-            got = np.concatenate([ctx.grads_get(g) for g in range(3)])
-            ok, info = grad_close(got, np.concatenate([ref.gradW, ref.grada, ref.gradWo]), 1e-3)
-            assert ok, (heads, info)
+            parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx)
             ctx.close()
+        parity.flush()
         print("OK")
     """)
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)

@@ -128,7 +128,8 @@ def test_optimizer_and_clip(orc):
 def test_restructured_cpu_step_matches_literal(orc, heads, outdims):
     """bench.py's second CPU line (PL/PR projections, O(E) softmax backward, message rows summed
     source-major — the HIP path's algorithm on host cores) against the literal restatement."""
-    from conftest import grad_close, small_graph
+    import parity
+    from conftest import small_graph
     rng = np.random.default_rng(8)
     n, f, c = 70, 9, 4
     rp, ci = small_graph(rng, n, 500, hub=(3, 90), empty=(0, 11))
@@ -139,6 +140,5 @@ def test_restructured_cpu_step_matches_literal(orc, heads, outdims):
     ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
     loss, correct, gW, ga, gWo = orc.step_restructured(cfg, rp, ci, lab, x, W, a, Wo)
     assert abs(loss - ref.loss_sum_f64) < 1e-4 * n and correct == ref.n_correct
-    for got, want in ((gW, ref.gradW), (ga, ref.grada), (gWo, ref.gradWo)):
-        ok, info = grad_close(got, want, 1e-4, frac=0.02)
-        assert ok, info
+    for name, got, want in (("gradW", gW, ref.gradW), ("grada", ga, ref.grada), ("gradWo", gWo, ref.gradWo)):
+        parity.check_rel(name, got, want, 1e-4)

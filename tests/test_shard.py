@@ -8,7 +8,8 @@ import tempfile
 import numpy as np
 import pytest
 
-from conftest import grad_close, small_graph
+import parity
+from conftest import small_graph
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -40,6 +41,46 @@ def test_partition_and_remap(pkg):
             assert ci_l.max(initial=0) < pl.n_table and pl.table_row0 == r * pl.max_rows
 
 
+def _hub_last_cases():
+    """Row pointers whose LAST rows hold >= E/world of the edges: several cuts land on n."""
+    yield np.array([0, 1, 2, 3, 100], np.int32)
+    yield np.array([0, 1, 2, 3, 4, 5, 100], np.int32)
+    yield np.array([0, 0, 0, 0, 0, 0, 0, 0, 50], np.int32)            # everything in the last row
+    yield np.array([0, 60, 60, 60, 60, 60, 60, 60, 60, 61], np.int32) # everything in the first row
+    yield np.concatenate([np.arange(40), [500, 1000, 5000]]).astype(np.int32)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_bounds_with_hub_in_last_rows_python_and_cxx(pkg, world, tmp_path):
+    """edge_balanced_bounds keeps bounds[-1] == n and strictly increasing cuts, in shard.py and in
+    host/shard_plan.h (same numbers), and local_csr stays inside row_ptr."""
+    import subprocess
+    S = pkg.shard
+    exe = tmp_path / "shard_plan_check"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "graph-attention-network-gatv2-_amd", "host"),
+                           os.path.join(ROOT, "tests", "cxx", "shard_plan_check.cpp"), "-o", str(exe)])
+    for rp in _hub_last_cases():
+        n = len(rp) - 1
+        if world > n:
+            with pytest.raises(ValueError):
+                S.edge_balanced_bounds(rp, world)
+            continue
+        b = S.edge_balanced_bounds(rp, world)
+        assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 1), (rp, world, b)
+        ci = np.zeros(int(rp[-1]), np.int32)
+        total = 0
+        for r in range(world):
+            rp_l, ci_l = S.local_csr(S.make_plan(rp, world, r), rp, ci)
+            assert rp_l[0] == 0 and rp_l[-1] == len(ci_l)
+            total += len(ci_l)
+        assert total == int(rp[-1])
+        out = subprocess.run([str(exe)], input=f"{world} {n} " + " ".join(map(str, rp)), capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = out.stdout.strip().splitlines()
+        assert lines[0].split()[1:] == [str(int(v)) for v in b], (lines[0], b)
+        assert sum(int(l.split()[5]) for l in lines[1:]) == int(rp[-1])
+
+
 def test_fake_context_matches_oracle_single_rank(pkg, orc):
     """The numpy stand-in used by the gloo tests is itself checked against the literal oracle."""
     from fake_ctx import FakeContext
@@ -65,8 +106,25 @@ def test_fake_context_matches_oracle_single_rank(pkg, orc):
     assert abs(loss - ref.loss_sum_f64) < 1e-4 * P["n"] and correct == ref.n_correct
     got = run.grads.numpy()
     want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
-    ok, info = grad_close(got, want, 1e-4, frac=0.02)
-    assert ok, info
+    parity.check_rel("fake context vs oracle", got, want, 1e-4)
+
+
+def _want(pkg, orc, P, W, a, Wo, ref, use_gpu):
+    """What every rank's reduced gradient is compared with, and the tolerance.  CPU (numpy stand-in of the
+    context): the literal oracle, 1e-4.  GPU: SURVEY 8e's contract — the P-shard result equals the ONE-GPU HIP
+    result within 1e-5 (same kernels, same per-row sums; only the order of the cross-shard sums differs) — and
+    that one-GPU result is itself held to the oracle at 1e-4 with the kink bookkeeping of tests/parity.py."""
+    if not use_gpu:
+        return np.concatenate([ref.gradW, ref.grada, ref.gradWo]), 1e-4
+    A = pkg.abi
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    with pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"]) as ctx:
+        ctx.set_graph(P["rp"], P["ci"]); ctx.set_features(P["x"]); ctx.set_labels(P["lab"])
+        for g, arr in enumerate((W, a, Wo)):
+            ctx.params_set(g, arr)
+        ctx.zero_grad(); ctx.forward(); ctx.backward()
+        parity.check_context_gradients(orc, A, cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo, ref, ctx, prefix="1gpu:")
+        return np.concatenate([ctx.grads_get(g) for g in range(3)]), 1e-5
 
 
 def _worker(rank, world, port, outdir, use_gpu, replicate):
@@ -127,7 +185,7 @@ def _run_world(world, use_gpu, pkg, orc, replicate=False):
     cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
     W, a, Wo = orc.xavier_params(cfg, 11)
     ref = orc.step(cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo)
-    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    want, tol = _want(pkg, orc, P, W, a, Wo, ref, use_gpu)
     port = 29500 + (os.getpid() % 2000) + world
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, port, d, use_gpu, replicate), nprocs=world, join=True)
@@ -135,8 +193,7 @@ def _run_world(world, use_gpu, pkg, orc, replicate=False):
     for o in outs:       # every rank holds the global loss and the all-reduced gradients
         assert abs(float(o["loss"]) - ref.loss_sum_f64) < 1e-4 * P["n"]
         assert int(o["correct"]) == ref.n_correct
-        ok, info = grad_close(o["grads"], want, 1e-3 if use_gpu else 2e-4, frac=0.02)   # fp32 HIP vs fp64 stand-in
-        assert ok, info
+        parity.check_rel(f"world{world}", o["grads"], want, tol)
     assert np.array_equal(outs[0]["grads"], outs[-1]["grads"])
 
 
@@ -166,10 +223,10 @@ def _run_virtual_ranks(world, use_gpu, replicate, pkg, orc):
     cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
     W, a, Wo = orc.xavier_params(cfg, 11)
     ref = orc.step(cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo)
-    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    want, tol = _want(pkg, orc, P, W, a, Wo, ref, use_gpu)
     S = pkg.shard
     hub = Hub(world, sync=(lambda: torch.cuda.synchronize()) if use_gpu else None)
-    results, errors = [None] * world, []
+    results, errors, twice = [None] * world, [], [None] * world
 
     def rank_main(rank):
         try:
@@ -199,6 +256,10 @@ def _run_virtual_ranks(world, use_gpu, replicate, pkg, orc):
             run = S.ShardedGat(ctx, plan, LoopbackComm(hub, rank), P["heads"], P["outdims"], alloc=alloc)
             loss, correct = run.step()
             results[rank] = (loss, correct, run.grads.cpu().numpy().copy())
+            # a second step WITHOUT zero_grad: the buffer accumulates (E:1631-1633 zeroes per epoch) and must hold
+            # exactly two steps' worth — not the first step re-reduced (x world) plus the second
+            run.step()
+            twice[rank] = run.grads.cpu().numpy().copy()
             if use_gpu:
                 ctx.close()
         except BaseException as ex:       # noqa: BLE001 - report and release the other threads
@@ -213,9 +274,10 @@ def _run_virtual_ranks(world, use_gpu, replicate, pkg, orc):
     assert not errors, errors
     for loss, correct, grads in results:
         assert abs(loss - ref.loss_sum_f64) < 1e-4 * P["n"] and correct == ref.n_correct
-        ok, info = grad_close(grads, want, 1e-3 if use_gpu else 2e-4, frac=0.02)
-        assert ok, info
+        parity.check_rel(f"virtual world{world}", grads, want, tol)
         assert np.array_equal(grads, results[0][2])          # fixed-order sums: identical on every rank
+    for r in range(world):
+        parity.check_rel(f"two steps without zero_grad, rank {r}", twice[r], 2.0 * results[r][2], 1e-5)
 
 
 @pytest.mark.parametrize("world,replicate", [(4, False), (8, True)])
@@ -256,7 +318,11 @@ def _comm_worker(rank, world, outdir, shm):
     loss2, correct2 = ctx.step()             # fused: one all-reduce
     grads2 = np.concatenate([ctx.grads_get(g) for g in range(3)])
     assert correct2 == correct and abs(loss2 - loss) < 1e-5 * max(1.0, abs(loss)) and np.array_equal(grads, grads2)
-    np.savez(os.path.join(outdir, f"r{rank}.npz"), loss=loss, correct=correct, grads=grads)
+    ctx.step()                               # no zero_grad in between: accumulates, reduced exactly once per step
+    grads_twice = np.concatenate([ctx.grads_get(g) for g in range(3)])
+    ctx.zero_grad(); ctx.forward(); ctx.backward(); ctx.backward()      # same contract for gat_backward
+    assert np.allclose(np.concatenate([ctx.grads_get(g) for g in range(3)]), grads_twice, rtol=1e-5, atol=1e-6 * np.abs(grads).max())
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), loss=loss, correct=correct, grads=grads, grads_twice=grads_twice)
     ctx.close()
 
 
@@ -270,15 +336,15 @@ def test_library_transport_host_processes_one_gpu(pkg, orc, world):
     cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
     W, a, Wo = orc.xavier_params(cfg, 11)
     ref = orc.step(cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo)
-    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    want, tol = _want(pkg, orc, P, W, a, Wo, ref, True)
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_comm_worker, args=(world, d, f"/gatv2_test_{os.getpid()}_{world}"), nprocs=world, join=True)
         outs = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
     for o in outs:
         assert abs(float(o["loss"]) - ref.loss_sum_f64) < 1e-4 * P["n"] and int(o["correct"]) == ref.n_correct
-        ok, info = grad_close(o["grads"], want, 1e-3, frac=0.02)
-        assert ok, info
+        parity.check_rel(f"host transport world{world}", o["grads"], want, tol)
         assert np.array_equal(o["grads"], outs[0]["grads"])
+        parity.check_rel("two steps without zero_grad", o["grads_twice"], 2.0 * o["grads"], 1e-5)
 
 
 @pytest.mark.gpu
@@ -289,7 +355,7 @@ def test_library_transport_rccl_world1(pkg, orc):
     cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
     W, a, Wo = orc.xavier_params(cfg, 11)
     ref = orc.step(cfg, P["rp"], P["ci"], P["lab"], P["x"], W, a, Wo)
-    want = np.concatenate([ref.gradW, ref.grada, ref.gradWo])
+    want, tol = _want(pkg, orc, P, W, a, Wo, ref, True)
     n_table = P["n"] + 8                     # one shard, 8 padding rows: n_table != n_rows => exchanges run
     ctx = pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"], device=0, collect_timing=True)
     ctx.set_graph(P["rp"], P["ci"], n_table=n_table, table_row0=0)
@@ -304,5 +370,4 @@ def test_library_transport_rccl_world1(pkg, orc):
     ctx.close()
     assert launches == 2 + 2 + 1             # all-gather and reduce-scatter per layer, one all-reduce
     assert abs(loss - ref.loss_sum_f64) < 1e-4 * P["n"] and correct == ref.n_correct
-    ok, info = grad_close(grads, want, 1e-3, frac=0.02)
-    assert ok, info
+    parity.check_rel("rccl world 1", grads, want, tol)

@@ -37,6 +37,10 @@ def test_cli_errors(args, msg):
     r = run(args)
     assert r.returncode == 1
     assert r.stderr.endswith(msg), r.stderr
+    # the reference prints its "[Memory Tracker] Before allocation" block before it looks at argv (E:929-933 vs
+    # E:943): the argument-error exits still show it
+    assert r.stdout.startswith("\n[Memory Tracker] Before allocation:\n  Total GPU memory: "), r.stdout
+    assert "Configuration:" not in r.stdout
 
 
 def test_cli_config_echo_and_missing_dataset(tmp_path):
