@@ -524,7 +524,20 @@ float orc_clip_grad_norm(float* grad, int64_t n, float thresh) {
 int orc_step_restructured(int L, const int* heads, const int* outdims, int F0, int C, int N, int E,
                           const int* row_ptr, const int* col_idx, const int* labels, const float* X0,
                           const float* W, const float* a, const float* Wo, float slope, double* loss_sum,
-                          int* n_correct, float* gradW, float* grada, float* gradWo) {
+                          int* n_correct, float* gradW, float* grada, float* gradWo, int acc64,
+                          const uint8_t* sbits, const uint8_t* hbits, int64_t* flip_count, float* flip_max_abs) {
+    // sbits / hbits (both or neither; tests at BASELINE's full sizes): the LeakyReLU' decisions to USE instead of
+    // this function's own `v > 0` — bit (e*HD + c) of layer l's block for s[e][c] = PL[src][c] + PR[dst][c], bit
+    // (n*HD + c) for h_pre[n][c]; layer blocks back to back, each rounded up to whole bytes, LSB first.  The tests
+    // pass the decisions the HIP path took (computed from its PL / PR / h_pre taps), so that the two fp32
+    // evaluations differ by round-off only and not by the finite jumps of LReLU' at pre-activations that are
+    // within round-off of 0 (E:599, 774, 855, 890).  flip_count[2l], [2l+1] / flip_max_abs[..]: how many s / h_pre
+    // decisions differed from this function's own, and the largest |value| among them — the caller asserts that
+    // they are few and all AT the kink (|value| ~ 1e-6), i.e. that no decision was wrong, only differently rounded.
+    // acc64 = 1 (tests at BASELINE's full sizes): the three PARAMETER-gradient reductions (over all nodes / edges)
+    // accumulate in double.  A float accumulator over 2.45 M terms carries ~1e-4 of relative round-off by itself —
+    // as much as the tolerance the checker enforces — and the reference's own float atomics (E:769-793) have no
+    // defined order to mimic.  Everything per edge / per row stays fp32.  acc64 = 0: bench.py's timed CPU line.
     struct Lay { int H, D, HD, F; int64_t woff, aoff; std::vector<float> PL, PR, alpha, hpre, hout, g; };
     std::vector<Lay> ly(L);
     int64_t woff = 0, aoff = 0;
@@ -534,6 +547,25 @@ int orc_step_restructured(int L, const int* heads, const int* outdims, int F0, i
         y.woff = woff; y.aoff = aoff;
         woff += (int64_t)y.HD * 2 * y.F; aoff += y.HD;
     }
+    std::vector<const uint8_t*> sb(L, nullptr), hb(L, nullptr);
+    if (sbits && hbits) {
+        const uint8_t *ps = sbits, *ph = hbits;
+        for (int l = 0; l < L; ++l) {
+            sb[l] = ps; ps += ((int64_t)E * ly[l].HD + 7) / 8;
+            hb[l] = ph; ph += ((int64_t)N * ly[l].HD + 7) / 8;
+        }
+    }
+    auto bit = [](const uint8_t* p, int64_t i) { return (p[i >> 3] >> (i & 7)) & 1; };
+    std::vector<int64_t> fc(2 * (size_t)L, 0);
+    std::vector<float> fm(2 * (size_t)L, 0.f);
+    // decision for value v at bit index i of block p (p == nullptr: the function's own); differences are tallied
+    auto decide = [&](const uint8_t* p, int64_t i, float v, int64_t& cnt, float& mx) -> float {
+        const bool own = v > 0.0f;
+        if (!p) return own ? 1.0f : slope;
+        const bool use = bit(p, i) != 0;
+        if (use != own) { ++cnt; mx = std::max(mx, std::fabs(v)); }
+        return use ? 1.0f : slope;
+    };
     // source-major slot of every edge (stable: fixed summation order)
     std::vector<int> sptr(N + 1, 0), pos(E);
     for (int e = 0; e < E; ++e) sptr[col_idx[e] + 1]++;
@@ -597,8 +629,9 @@ int orc_step_restructured(int L, const int* heads, const int* outdims, int F0, i
     yl.g.assign((size_t)N * yl.HD, 0.f);
     double loss = 0.0; long correct = 0;
     const int T = orc_num_threads();
-    std::vector<std::vector<float>> pWo(T, std::vector<float>((size_t)C * DL, 0.f));
-#pragma omp parallel reduction(+ : loss, correct)
+    std::vector<std::vector<double>> pWo(T, std::vector<double>((size_t)C * DL, 0.0));   // tiny: always double
+    int64_t hcnt_last = 0; float hmax_last = 0.f;
+#pragma omp parallel reduction(+ : loss, correct, hcnt_last) reduction(max : hmax_last)
     {
 #ifdef _OPENMP
         const int tid = omp_get_thread_num();
@@ -623,19 +656,20 @@ int orc_step_restructured(int L, const int* heads, const int* outdims, int F0, i
             correct += pred == labels[n];
             z[labels[n]] -= 1.0f;                                             // dz
             for (int c = 0; c < C; ++c)
-                for (int d = 0; d < DL; ++d) pWo[tid][c * DL + d] += z[c] * hl[d];
+                for (int d = 0; d < DL; ++d) pWo[tid][c * DL + d] += (double)(z[c] * hl[d]);
             for (int d = 0; d < DL; ++d) {
                 float gh = 0.f;
                 for (int c = 0; c < C; ++c) gh += Wo[c * DL + d] * z[c];
                 for (int h = 0; h < HL; ++h) {
                     const size_t i = (size_t)n * yl.HD + h * DL + d;
-                    yl.g[i] = gh * dlrelu(yl.hpre[i], slope) / (float)HL;
+                    yl.g[i] = gh * decide(hb[L - 1], (int64_t)i, yl.hpre[i], hcnt_last, hmax_last) / (float)HL;
                 }
             }
         }
     }
-    for (int t = 0; t < T; ++t) for (int i = 0; i < C * DL; ++i) gradWo[i] += pWo[t][i];
+    for (int i = 0; i < C * DL; ++i) { double t_ = 0.0; for (int t = 0; t < T; ++t) t_ += pWo[t][i]; gradWo[i] += (float)t_; }
     *loss_sum = loss; *n_correct = (int)correct;
+    fc[2 * (size_t)(L - 1) + 1] = hcnt_last; fm[2 * (size_t)(L - 1) + 1] = hmax_last;
 
     std::vector<float> msg, gPL, gPR;
     for (int l = L - 1; l >= 0; --l) {                                       // ---- backward
@@ -644,8 +678,9 @@ int orc_step_restructured(int L, const int* heads, const int* outdims, int F0, i
         const float* Wl = W + y.woff; const float* al = a + y.aoff;
         const float* X = l == 0 ? X0 : ly[l - 1].hout.data();
         msg.assign((size_t)E * HD, 0.f); gPL.assign((size_t)N * HD, 0.f); gPR.assign((size_t)N * HD, 0.f);
-        std::vector<std::vector<float>> pa(T, std::vector<float>(HD, 0.f));
-#pragma omp parallel
+        std::vector<std::vector<double>> pa(T, std::vector<double>(HD, 0.0));            // tiny: always double
+        int64_t scnt = 0; float smax = 0.f;
+#pragma omp parallel reduction(+ : scnt) reduction(max : smax)
         {
 #ifdef _OPENMP
             const int tid = omp_get_thread_num();
@@ -670,8 +705,8 @@ int orc_step_restructured(int L, const int* heads, const int* outdims, int F0, i
                         for (int k = 0; k < D; ++k) {
                             const int c = h * D + k;
                             const float sv = pl[c] + pr[c];
-                            const float gs = ge * al[c] * dlrelu(sv, slope);
-                            pa[tid][c] += ge * lrelu(sv, slope);
+                            const float gs = ge * al[c] * decide(sb[l], (int64_t)e * HD + c, sv, scnt, smax);
+                            pa[tid][c] += (double)(ge * lrelu(sv, slope));
                             gpr[c] += gs;
                             m[c] = g[c] * al_e + gs;
                         }
@@ -685,41 +720,51 @@ int orc_step_restructured(int L, const int* heads, const int* outdims, int F0, i
                     for (int c = 0; c < HD; ++c) o[c] += msg[(size_t)i * HD + c];
             }
         }
-        for (int t = 0; t < T; ++t) for (int c = 0; c < HD; ++c) grada[y.aoff + c] += pa[t][c];
+        for (int c = 0; c < HD; ++c) { double t_ = 0.0; for (int t = 0; t < T; ++t) t_ += pa[t][c]; grada[y.aoff + c] += (float)t_; }
+        fc[2 * (size_t)l] = scnt; fm[2 * (size_t)l] = smax;
         // gradW[j][0:F] += sum_n gPL[n][j] X[n][:],  [F:2F] with gPR  (thread-local slabs, summed in thread order)
-        std::vector<std::vector<float>> pw(T, std::vector<float>((size_t)HD * 2 * F, 0.f));
+        const size_t nw = (size_t)HD * 2 * F;
+        auto grad_w = [&](auto zero) {
+            using Acc = decltype(zero);
+            std::vector<std::vector<Acc>> pw(T, std::vector<Acc>(nw, zero));
 #pragma omp parallel
-        {
+            {
 #ifdef _OPENMP
-            const int tid = omp_get_thread_num();
+                const int tid = omp_get_thread_num();
 #else
-            const int tid = 0;
+                const int tid = 0;
 #endif
-            float* w = pw[tid].data();
+                Acc* w = pw[tid].data();
 #pragma omp for schedule(static)
-            for (int n = 0; n < N; ++n) {
-                const float* x = X + (size_t)n * F;
-                for (int j = 0; j < HD; ++j) {
-                    const float gl = gPL[(size_t)n * HD + j], gr = gPR[(size_t)n * HD + j];
-                    float* wj = w + (size_t)j * 2 * F;
-                    for (int f = 0; f < F; ++f) { wj[f] += gl * x[f]; wj[F + f] += gr * x[f]; }
+                for (int n = 0; n < N; ++n) {
+                    const float* x = X + (size_t)n * F;
+                    for (int j = 0; j < HD; ++j) {
+                        const float gl = gPL[(size_t)n * HD + j], gr = gPR[(size_t)n * HD + j];
+                        Acc* wj = w + (size_t)j * 2 * F;
+                        for (int f = 0; f < F; ++f) { wj[f] += (Acc)(gl * x[f]); wj[F + f] += (Acc)(gr * x[f]); }
+                    }
                 }
             }
-        }
-        for (int t = 0; t < T; ++t) for (int64_t i = 0; i < (int64_t)HD * 2 * F; ++i) gradW[y.woff + i] += pw[t][i];
+            for (size_t i = 0; i < nw; ++i) { Acc t_ = zero; for (int t = 0; t < T; ++t) t_ += pw[t][i]; gradW[y.woff + i] += (float)t_; }
+        };
+        if (acc64) grad_w(0.0); else grad_w(0.0f);
         if (l > 0) {
             Lay& yp = ly[l - 1];
             yp.g.assign((size_t)N * yp.HD, 0.f);
-#pragma omp parallel for schedule(static)
+            int64_t hcnt = 0; float hmax = 0.f;
+#pragma omp parallel for schedule(static) reduction(+ : hcnt) reduction(max : hmax)
             for (int n = 0; n < N; ++n)
                 for (int f = 0; f < F; ++f) {
                     float t = 0.f;
                     for (int j = 0; j < HD; ++j)
                         t += gPL[(size_t)n * HD + j] * Wl[(size_t)j * 2 * F + f] + gPR[(size_t)n * HD + j] * Wl[(size_t)j * 2 * F + F + f];
-                    yp.g[(size_t)n * F + f] = t * dlrelu(yp.hpre[(size_t)n * F + f], slope);
+                    yp.g[(size_t)n * F + f] = t * decide(hb[l - 1], (int64_t)n * F + f, yp.hpre[(size_t)n * F + f], hcnt, hmax);
                 }
+            fc[2 * (size_t)(l - 1) + 1] = hcnt; fm[2 * (size_t)(l - 1) + 1] = hmax;
         }
     }
+    if (flip_count) for (size_t i = 0; i < fc.size(); ++i) flip_count[i] = fc[i];
+    if (flip_max_abs) for (size_t i = 0; i < fm.size(); ++i) flip_max_abs[i] = fm[i];
     return 0;
 }
 

@@ -80,7 +80,8 @@ def lib() -> C.CDLL:
         "orc_adam": ([f32p, f32p, f32p, f32p, f, C.c_int64, f, f, f, i], None),
         "orc_clip_grad_norm": ([f32p, C.c_int64, f], f),
         "orc_step_restructured": ([i, i32p, i32p, i, i, i, i, i32p, i32p, i32p, f32p, f32p, f32p, f32p, f,
-                                   C.POINTER(C.c_double), C.POINTER(i), f32p, f32p, f32p], i),
+                                   C.POINTER(C.c_double), C.POINTER(i), f32p, f32p, f32p, i,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], i),
     }
     for name, (argt, rest) in sig.items():
         fn = getattr(L, name)
@@ -272,10 +273,12 @@ def presum_signs(cfg: Config, row_ptr, col_idx, X0, W, ref: "StepResult"):
     return out_lr, out_il
 
 
-def step_restructured(cfg: Config, row_ptr, col_idx, labels, X0, W, a, Wo):
+def step_restructured(cfg: Config, row_ptr, col_idx, labels, X0, W, a, Wo, acc64: bool = False, decisions=None):
     """One forward + backward with the RESTRUCTURED algorithm (the one the HIP path uses) on the host
     cores: bench.py's second CPU line; not a restatement of the reference's kernels.
-    -> (loss_sum, n_correct, gradW, grada, gradWo)"""
+    decisions = (sbits, hbits): packed LeakyReLU' decisions to use (see orc_step_restructured); the result then
+    carries ``flips`` = (counts int64 [L][2], max |value| at a differing decision float32 [L][2]).
+    -> (loss_sum, n_correct, gradW, grada, gradWo[, flips])"""
     Lb = lib()
     row_ptr = np.ascontiguousarray(row_ptr, np.int32); col_idx = np.ascontiguousarray(col_idx, np.int32)
     labels = np.ascontiguousarray(labels, np.int32); X0 = np.ascontiguousarray(X0, np.float32)
@@ -284,8 +287,19 @@ def step_restructured(cfg: Config, row_ptr, col_idx, labels, X0, W, a, Wo):
     heads = np.asarray(cfg.heads, np.int32); outdims = np.asarray(cfg.outdims, np.int32)
     gW, ga, gWo = np.zeros_like(W), np.zeros_like(a), np.zeros_like(Wo)
     loss, corr = C.c_double(), C.c_int()
+    sb = hb = fc = fm = None
+    cnt = np.zeros((cfg.L, 2), np.int64); mx = np.zeros((cfg.L, 2), np.float32)
+    if decisions is not None:
+        sbits = np.ascontiguousarray(decisions[0], np.uint8); hbits = np.ascontiguousarray(decisions[1], np.uint8)
+        N, E = len(row_ptr) - 1, len(col_idx)
+        assert sbits.size == sum((E * h * d + 7) // 8 for h, d in zip(cfg.heads, cfg.outdims))
+        assert hbits.size == sum((N * h * d + 7) // 8 for h, d in zip(cfg.heads, cfg.outdims))
+        sb, hb = sbits.ctypes.data, hbits.ctypes.data
+        fc, fm = cnt.ctypes.data, mx.ctypes.data
     rc = Lb.orc_step_restructured(cfg.L, heads, outdims, cfg.in_dim0, cfg.num_classes, len(row_ptr) - 1, len(col_idx),
                                   row_ptr, col_idx, labels, X0, W, a, Wo, NEG_SLOPE, C.byref(loss), C.byref(corr),
-                                  gW, ga, gWo)
+                                  gW, ga, gWo, int(acc64), sb, hb, fc, fm)
     assert rc == 0
+    if decisions is not None:
+        return loss.value, corr.value, gW, ga, gWo, (cnt, mx)
     return loss.value, corr.value, gW, ga, gWo

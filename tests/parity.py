@@ -144,7 +144,7 @@ def expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, m
 
 
 def check_context_gradients(orc, A, cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, ctx, taps=False, prefix="",
-                            max_flips=MAX_FLIPS):
+                            max_flips=MAX_FLIPS, floor=1e-12):
     """The whole gradient comparison of one context after forward+backward against the oracle result `ref`, at
     GTOL with the kink bookkeeping above.  taps=True also compares g, galpha, ge and gx per layer (needs a
     context created with keep_taps=True).  -> Flips"""
@@ -157,7 +157,38 @@ def check_context_gradients(orc, A, cfg, row_ptr, col_idx, labels, x, W, a, Wo, 
             check_rel(f"{prefix}ge[{l}]", ctx.tap(A.TAP_GE, l), exp["ge"][l])
             if l > 0:
                 check_rel(f"{prefix}gx[{l}]", ctx.tap(A.TAP_GX, l), exp["gx"][l])
-    check_rel(f"{prefix}gradWo", ctx.grads_get(A.PARAM_WO), exp["gradWo"])
-    check_rel(f"{prefix}grada", ctx.grads_get(A.PARAM_A), exp["grada"])
-    check_rel(f"{prefix}gradW", ctx.grads_get(A.PARAM_W), exp["gradW"])
+    # floor: lower bound of the scale the error is measured against — only for graphs on which a tensor cancels to
+    # ~0 analytically (one in-edge per row: alpha == 1, grad_attn_score == 0, grad_a == 0 up to round-off)
+    check_rel(f"{prefix}gradWo", ctx.grads_get(A.PARAM_WO), exp["gradWo"], floor=floor)
+    check_rel(f"{prefix}grada", ctx.grads_get(A.PARAM_A), exp["grada"], floor=floor)
+    check_rel(f"{prefix}gradW", ctx.grads_get(A.PARAM_W), exp["gradW"], floor=floor)
     return flips
+
+
+def pack_decisions(cfg, row_ptr, col_idx, PLs, PRs, hpres, chunk=1 << 22):
+    """LeakyReLU' decisions of a path, packed for orc_step_restructured(decisions=...): per layer, bit (e*HD + c) =
+    fl32(PL[src_e][c] + PR[dst_e][c]) > 0 — the kernels' own `v + pr` — and bit (n*HD + c) = h_pre[n][c] > 0.
+    Edge chunks keep the temporaries at ~1 GB for the 61.9 M-edge graph.  -> (sbits uint8, hbits uint8)"""
+    src = np.asarray(col_idx, np.int64)
+    deg = np.diff(np.asarray(row_ptr, np.int64))
+    dst = np.repeat(np.arange(len(deg), dtype=np.int64), deg)
+    sb, hb = [], []
+    for l in range(cfg.L):
+        HD = cfg.heads[l] * cfg.outdims[l]
+        PL = np.asarray(PLs[l], np.float32).reshape(-1, HD); PR = np.asarray(PRs[l], np.float32).reshape(-1, HD)
+        assert (chunk * HD) % 8 == 0
+        parts = []
+        for lo in range(0, len(src), chunk):
+            s = PL[src[lo:lo + chunk]]
+            s += PR[dst[lo:lo + chunk]]
+            parts.append(np.packbits((s > 0).reshape(-1), bitorder="little"))
+        sb.append(np.concatenate(parts) if parts else np.zeros(0, np.uint8))
+        hb.append(np.packbits((np.asarray(hpres[l]) > 0).reshape(-1), bitorder="little"))
+    return np.concatenate(sb), np.concatenate(hb)
+
+
+def context_decisions(ctx, A, cfg, row_ptr, col_idx):
+    """pack_decisions of a HIP context after its forward (PL / PR / h_pre taps need no keep_taps)."""
+    L = range(cfg.L)
+    return pack_decisions(cfg, row_ptr, col_idx, [ctx.tap(A.TAP_PL, l) for l in L], [ctx.tap(A.TAP_PR, l) for l in L],
+                          [ctx.tap(A.TAP_HPRE, l) for l in L])

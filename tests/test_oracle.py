@@ -124,8 +124,9 @@ def test_optimizer_and_clip(orc):
     assert np.allclose(p2, p - 0.01 * np.sign(g), atol=1e-4)        # first Adam step == lr*sign(g)
 
 
+@pytest.mark.parametrize("acc64", [False, True])
 @pytest.mark.parametrize("heads,outdims", [((8, 8), (8, 8)), ((3, 1), (4, 5)), ((2, 2, 1), (4, 4, 8))])
-def test_restructured_cpu_step_matches_literal(orc, heads, outdims):
+def test_restructured_cpu_step_matches_literal(orc, heads, outdims, acc64):
     """bench.py's second CPU line (PL/PR projections, O(E) softmax backward, message rows summed
     source-major — the HIP path's algorithm on host cores) against the literal restatement."""
     import parity
@@ -138,7 +139,7 @@ def test_restructured_cpu_step_matches_literal(orc, heads, outdims):
     cfg = orc.Config(list(heads), list(outdims), f, c)
     W, a, Wo = orc.xavier_params(cfg, 2)
     ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
-    loss, correct, gW, ga, gWo = orc.step_restructured(cfg, rp, ci, lab, x, W, a, Wo)
+    loss, correct, gW, ga, gWo = orc.step_restructured(cfg, rp, ci, lab, x, W, a, Wo, acc64=acc64)
     assert abs(loss - ref.loss_sum_f64) < 1e-4 * n and correct == ref.n_correct
     for name, got, want in (("gradW", gW, ref.gradW), ("grada", ga, ref.grada), ("gradWo", gWo, ref.gradWo)):
         parity.check_rel(name, got, want, 1e-4)

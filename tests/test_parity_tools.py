@@ -105,3 +105,38 @@ def test_expected_gradients_without_flips_is_the_oracle(orc):
     assert np.array_equal(exp["g"][1], ref.taps["g"][1])
     d = exp["g"][0] - ref.taps["g"][0]
     assert np.count_nonzero(d) == 1 and d[5, 1, 2] != 0
+
+
+def test_forced_decisions_in_the_restructured_checker(orc):
+    """orc_step_restructured(decisions=...): its own decisions packed and fed back change nothing and report no
+    flips; one flipped s-decision changes the parameter gradients by exactly what tests/ref64.py computes for that
+    flip (the two kink mechanisms agree), and is reported with the |s| it happened at."""
+    cfg, rp, ci, lab, x, W, a, Wo = _case(orc, n=60, e=400, heads=(8, 8), outdims=(8, 8), f=12)
+    base = orc.step_restructured(cfg, rp, ci, lab, x, W, a, Wo, acc64=True)
+    fw = ref64.forward(cfg, rp, ci, lab, x, W, a, Wo)           # fp64 twin: same signs except within round-off of 0
+    PLs = [y["PL"].reshape(len(rp) - 1, -1).astype(np.float32) for y in fw["layers"]]
+    PRs = [y["PR"].reshape(len(rp) - 1, -1).astype(np.float32) for y in fw["layers"]]
+    hps = [y["hpre"].astype(np.float32) for y in fw["layers"]]
+    sb, hb = parity.pack_decisions(cfg, rp, ci, PLs, PRs, hps, chunk=64)
+    same = orc.step_restructured(cfg, rp, ci, lab, x, W, a, Wo, acc64=True, decisions=(sb, hb))
+    cnt, mx = same[5]
+    assert cnt.sum() <= 2 and (mx < 1e-5).all()                 # fp64-vs-fp32 sign differences, if any, sit at the kink
+    if cnt.sum() == 0:
+        for u, v in zip(base[2:5], same[2:5]):
+            assert np.array_equal(u, v)
+    # flip one layer-1 decision: edge 17, channel 9
+    e, c, l = 17, 9, 1
+    HD0 = cfg.heads[0] * cfg.outdims[0]
+    off = (len(ci) * HD0 + 7) // 8 * 8 + e * 64 + c             # bit index inside the concatenated block
+    sb2 = sb.copy(); sb2[off >> 3] ^= np.uint8(1 << (off & 7))
+    flipped = orc.step_restructured(cfg, rp, ci, lab, x, W, a, Wo, acc64=True, decisions=(sb2, hb))
+    assert flipped[5][0][1, 0] == cnt[1, 0] + 1
+    ms = [y["s"] > 0 for y in fw["layers"]]; mh = [y["hpre"] > 0 for y in fw["layers"]]
+    m2 = [m.copy() for m in ms]; m2[l][e, c // 8, c % 8] ^= True
+    d64 = ref64.backward(cfg, fw, m2, m2, mh)
+    b64 = ref64.backward(cfg, fw, ms, ms, mh)
+    for k, i in (("gradW", 2), ("grada", 3), ("gradWo", 4)):
+        want = d64[k] - b64[k]
+        got = flipped[i].astype(np.float64) - same[i].astype(np.float64)
+        assert np.abs(got - want).max() <= 2e-5 * max(1e-9, np.abs(b64[k]).max()), k
+    assert np.abs(d64["gradW"] - b64["gradW"]).max() > 0
