@@ -67,7 +67,7 @@ def rel_err(got, want, floor=1e-12):
     got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
     if got.size == 0:
         return 0.0
-    return float(np.abs(got - want).max() / max(floor, np.abs(want).max()))
+    return float(np.abs(got - want).max() / max(floor, np.abs(want).max(), 1e-30))
 
 
 def check_rel(name, got, want, tol=GTOL, floor=1e-12, **extra):
