@@ -33,6 +33,7 @@ struct Layer {
     float* score = nullptr;   // [E][H]  (keep_taps) raw attention scores, E:323
     float* galpha = nullptr;  // [E][H]  (keep_taps) grad wrt attn_coeff, E:646
     float* mstat = nullptr;   // [n_rows][H] (keep_taps)
+    bool stash = false;       // backward scatter through per-edge records + pull pass (edge_stash_words) instead of message rows
     float* zstat = nullptr;
 };
 
@@ -101,6 +102,9 @@ struct gat_ctx {
     int4* gpl_chunks = nullptr; int4* gpl_heavy = nullptr; float* gpl_part = nullptr;   // long source lists (HeavyList)
     int32_t n_gpl_chunks = 0, n_gpl_heavy = 0;
     float* msg = nullptr; int32_t msg_hd = 0;       // [E][msg_hd] per-edge message rows (store path)
+    uint32_t* stash = nullptr; int32_t stash_words = 0;   // [E][stash_words] per-edge records (stash path: Layer::stash)
+    int32_t* csc_dst = nullptr;                     // [E] destination row of every slot (stash path)
+    float* gfull = nullptr;                         // [n_rows][HDmax] dL/dh_pre incl. LReLU' (stash path: gathered by the pull pass)
     int32_t dbg = 0;                                // GAT_DBG timing experiments (0 = product behaviour)
     gat::WorkList work;                             // host copy of the item list
     int4* items = nullptr; int4* slot_info = nullptr;
@@ -234,32 +238,51 @@ static int ensure_buffers(gat_ctx* c) {
     GAT_HIP(hipStreamSynchronize(c->stream));
     // Store-then-sum backward for the layers on the wave-per-row fast path: needs the source-major
     // slot index and an [E][H*D] scratch.  GAT_BWD_ATOMICS=1 forces the float-atomic variant (A/B).
-    int32_t msg_hd = 0;
-    for (int l = 0; l < L; ++l)
-        if (edge_fast_path(c->layers[l].H, c->layers[l].D, c->n_table)) msg_hd = std::max(msg_hd, c->layers[l].HD);
+    // Which form the per-edge scatter takes, per layer: the stash path (64-B records + one gathered row of g[dst] in
+    // the source-major pass) where the shape has one, else H*D-float message rows.  GAT_BWD_STASH=0 forces message
+    // rows everywhere (the A/B of DESIGN §4); the taps variant of the backward always uses message rows.
+    int32_t msg_hd = 0, stash_words = 0;
+    const char* no_stash = getenv("GAT_BWD_STASH");
+    for (int l = 0; l < L; ++l) {
+        Layer& y = c->layers[l];
+        if (!edge_fast_path(y.H, y.D, c->n_table)) continue;
+        const int w = edge_stash_words(y.H, y.D);
+        y.stash = w > 0 && !bf16(c) && !c->cfg.keep_taps && !(no_stash && no_stash[0] == '0');
+        if (y.stash) stash_words = std::max(stash_words, w); else msg_hd = std::max(msg_hd, y.HD);
+    }
     const char* force = getenv("GAT_BWD_ATOMICS");
-    if (msg_hd > 0 && E > 0 && !(force && force[0] == '1')) {
+    if ((msg_hd > 0 || stash_words > 0) && E > 0 && !(force && force[0] == '1')) {
         float* m = nullptr;
-        if (hipMalloc((void**)&m, (size_t)E * msg_hd * (size_t)st_bytes(c)) == hipSuccess) {
+        if (hipMalloc((void**)&m, std::max<size_t>((size_t)E * msg_hd * (size_t)st_bytes(c), (size_t)E * stash_words * sizeof(uint32_t))) == hipSuccess) {
             c->owned.push_back(m);
-            c->msg = m; c->msg_hd = msg_hd;
+            if (msg_hd > 0) { c->msg = m; c->msg_hd = msg_hd; }
+            if (stash_words > 0) {                  // records and message rows are never live at the same time: one buffer
+                c->stash = reinterpret_cast<uint32_t*>(m); c->stash_words = stash_words;
+                if (msg_hd == 0) { c->msg = m; c->msg_hd = 0; }
+                GAT_TRY(dalloc(c, &c->gfull, N * c->HDmax));
+                GAT_TRY(dalloc(c, &c->csc_dst, E));
+            }
             GAT_TRY(dalloc(c, &c->csc_pos, E));
             GAT_TRY(dalloc(c, &c->csc_ptr, T + 1));
             GAT_TRY(build_csc(c->col_idx, E, T, c->csc_pos, c->csc_ptr, c->stream));
+            if (c->csc_dst) GAT_TRY(build_csc_dst(c->row_ptr, c->csc_pos, c->csc_dst, N, E, c->stream));
             HeavyList hl;
             GAT_TRY(build_heavy_list(c->csc_ptr, T, &hl, c->stream));
             c->n_gpl_chunks = (int32_t)(hl.chunks.size() / 4); c->n_gpl_heavy = (int32_t)(hl.heavy.size() / 4);
             if (c->n_gpl_heavy > 0) {
                 GAT_TRY(dalloc(c, &c->gpl_chunks, c->n_gpl_chunks));
                 GAT_TRY(dalloc(c, &c->gpl_heavy, c->n_gpl_heavy));
-                GAT_TRY(dalloc(c, &c->gpl_part, (int64_t)c->n_gpl_chunks * msg_hd));
+                GAT_TRY(dalloc(c, &c->gpl_part, (int64_t)c->n_gpl_chunks * c->HDmax));
                 GAT_HIP(hipMemcpyAsync(c->gpl_chunks, hl.chunks.data(), hl.chunks.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
                 GAT_HIP(hipMemcpyAsync(c->gpl_heavy, hl.heavy.data(), hl.heavy.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
                 GAT_HIP(hipStreamSynchronize(c->stream));
             }
         } else {
             (void)hipGetLastError();      // not enough HBM for the scratch: atomics variant
+            for (int l = 0; l < L; ++l) c->layers[l].stash = false;
         }
+    } else {
+        for (int l = 0; l < L; ++l) c->layers[l].stash = false;
     }
     GAT_TRY(dalloc(c, &c->ga_partial, (int64_t)2048 * c->HDmax));      // >= any edge_backward_blocks()
     int64_t gw = 1;
@@ -632,6 +655,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     GAT_TRY(check_layer(c, l));
     Layer& y = c->layers[l];
     const bool store = c->msg != nullptr && edge_fast_path(y.H, y.D, c->n_table);
+    const bool stash = store && y.stash && c->stash != nullptr;
     if (!store) {
         Scope t(c, GAT_K_MISC);
         GAT_HIP(hipMemsetAsync(c->gPL, 0, (size_t)c->n_table * y.HD * sizeof(float), c->stream));
@@ -643,18 +667,24 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.g_raw = l < c->cfg.num_layers - 1;           // hidden layers: written by launch_grad_x without the LReLU' factor
     a.gh = (l == c->cfg.num_layers - 1) ? c->gH : nullptr;
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
+    a.stash = stash ? c->stash : nullptr; a.gfull = stash ? c->gfull : nullptr;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots; a.n_split = c->work.n_split;
     a.part_acc = c->part_acc;
     a.dbg = c->dbg;
     a.ga_partial = c->ga_partial; a.n_rows = c->n_rows; a.n_table = c->n_table; a.bf16 = bf16(c); a.H = y.H; a.D = y.D;
-    a.ga_blocks = edge_fast_path(y.H, y.D, c->n_table) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr, bf16(c))
+    a.ga_blocks = edge_fast_path(y.H, y.D, c->n_table) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr, bf16(c), stash)
                                            : edge_backward_blocks(c->n_rows * 4, y.H, y.D, false, false, false);
     a.slope = c->cfg.negative_slope;
     {
         Scope t(c, GAT_K_EDGE_BWD);
         GAT_TRY(launch_edge_backward(a, c->stream));
     }
-    if (store) {
+    if (stash) {
+        Scope t(c, GAT_K_GPL_SUM);
+        GAT_TRY(launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, a_of(c, l), c->cfg.negative_slope, c->gPL, c->n_table,
+                                c->n_edges, y.H, y.D, c->gpl_chunks, c->n_gpl_chunks, c->gpl_heavy, c->n_gpl_heavy, c->gpl_part,
+                                c->stream));
+    } else if (store) {
         Scope t(c, GAT_K_GPL_SUM);
         GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, bf16(c), c->gpl_chunks, c->n_gpl_chunks,
                                c->gpl_heavy, c->n_gpl_heavy, c->gpl_part, c->stream));

@@ -267,7 +267,171 @@ __global__ __launch_bounds__(256) void gpl_sum_group_kernel(const int32_t* __res
     if (s < n_table && !heavy) reinterpret_cast<float4*>(gPL)[s * LPR + q] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Stash path (edge_bwd2_kernel<..., STASH>): the destination-major backward leaves a record of HD/N words per edge
+// in its source-major slot — per head, alpha in the even lane's word and grad_attn_score in the odd lane's, each
+// with the N LeakyReLU'(s) decisions of that lane's channels in its N low bits — instead of the HD-float message
+// row.  This pass walks a source's slots, gathers ONE row g[dst] per edge and rebuilds
+//     msg[c] = g[dst][c] * alpha[h] + ge[h] * a[c] * (bit_c ? 1 : slope)                       (E:859-869)
+// while it sums: 64 B + 4 B streamed and 256 B gathered per edge (H*D = 64), against 256 B written and 256 B
+// re-read by the message-row path.  Same fixed summation order per source => bitwise reproducible.
+// Lane layout as in the edge kernels: N adjacent channels per lane, LPE = HD/N lanes per edge, G = 64/LPE edges per
+// wave-instruction; the chunk's destination indices come from one coalesced load and reach their lanes via shuffles.
+template <int N> struct PullVec;
+template <> struct PullVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct PullVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+template <int HD, int N>
+__device__ __forceinline__ typename PullVec<N>::T pull_range(const uint32_t* __restrict__ stash,
+                                                             const int32_t* __restrict__ cdst,
+                                                             const float* __restrict__ gfull, int b, int e, int lane,
+                                                             typename PullVec<N>::T ac, typename PullVec<N>::T acs) {
+    using V = typename PullVec<N>::T;
+    constexpr int LPE = HD / N, G = 64 / LPE;
+    constexpr int CH = 16, U = CH / G;
+    static_assert(U >= 1, "lane layout");
+    const int cp = lane % LPE, gidx = lane / LPE;
+    V acc;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = 0.f;
+    auto load_dst = [&](int i0) {
+        const int j = i0 + (lane & (CH - 1));
+        return cdst[j < e ? j : e - 1];
+    };
+    int dv = load_dst(b);                                   // callers pass b < e
+    for (int i0 = b; i0 < e; i0 += CH) {
+        const int dn = (i0 + CH < e) ? load_dst(i0 + CH) : 0;
+        uint32_t w[U];
+        V g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * G + gidx;
+            const int ic = i < e ? i : e - 1;                   // clamped: loads need no predicate
+            w[u] = stash[(uint64_t)(uint32_t)ic * LPE + cp];
+            const uint32_t off = (uint32_t)__shfl(dv, u * G + gidx) * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4);
+            g[u] = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * G + gidx;
+            const float val = __builtin_bit_cast(float, w[u] & ~((1u << N) - 1u));
+            const float oth = __shfl_xor(val, 1);               // the head's other lane: alpha <-> ge
+            const float al = (cp & 1) ? oth : val, ge = (cp & 1) ? val : oth;
+            V asel;
+#pragma unroll
+            for (int k = 0; k < N; ++k) asel[k] = (w[u] >> k) & 1u ? ac[k] : acs[k];
+            const float keep = i < e ? 1.0f : 0.0f;             // padded slots contribute nothing
+            acc += (g[u] * al + asel * ge) * keep;
+        }
+        dv = dn;
+    }
+#pragma unroll
+    for (int off = LPE; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] += __shfl_xor(acc[k], off);
+    return acc;
+}
+
+template <int HD, int N>
+__global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict__ src_ptr, const uint32_t* __restrict__ stash,
+                                                       const int32_t* __restrict__ cdst, const float* __restrict__ gfull,
+                                                       const float* __restrict__ a, float slope, float* __restrict__ gPL,
+                                                       int64_t n_table, int32_t kHeavySlots) {
+    using V = typename PullVec<N>::T;
+    constexpr int LPE = HD / N;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (s >= n_table) return;
+    const int b = src_ptr[s], e = src_ptr[s + 1];
+    if (e - b > kHeavySlots) return;                    // long lists: gpl_pull_chunk_kernel + gpl_heavy_fix_kernel
+    const int cp = lane % LPE;
+    V acc;
+    if (b < e) {
+        const V ac = *reinterpret_cast<const V*>(a + cp * N);
+        acc = pull_range<HD, N>(stash, cdst, gfull, b, e, lane, ac, ac * slope);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = 0.f;
+    }
+    if (lane < LPE) *reinterpret_cast<V*>(gPL + s * HD + cp * N) = acc;
+}
+
+template <int HD, int N>
+__global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restrict__ chunks, int32_t n_chunks,
+                                                             const uint32_t* __restrict__ stash, const int32_t* __restrict__ cdst,
+                                                             const float* __restrict__ gfull, const float* __restrict__ a,
+                                                             float slope, float* __restrict__ part) {
+    using V = typename PullVec<N>::T;
+    constexpr int LPE = HD / N;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= n_chunks) return;
+    const int4 ch = chunks[k];                          // {first slot, end slot, partial row, -}, never empty
+    const int cp = lane % LPE;
+    const V ac = *reinterpret_cast<const V*>(a + cp * N);
+    const V acc = pull_range<HD, N>(stash, cdst, gfull, ch.x, ch.y, lane, ac, ac * slope);
+    if (lane < LPE) *reinterpret_cast<V*>(part + (int64_t)ch.z * HD + cp * N) = acc;
+}
+
+// cdst[pos[e]] = row of CSR edge e (binary search in row_ptr, as csr_to_coo_kernel)
+__global__ __launch_bounds__(256) void csc_dst_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ pos,
+                                                     int32_t* __restrict__ cdst, int64_t n_rows, int64_t n_edges) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += stride) {
+        int64_t lo = 0, hi = n_rows;          // invariant: row_ptr[lo] <= e < row_ptr[hi]
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)row_ptr[mid] <= e) lo = mid; else hi = mid;
+        }
+        cdst[pos[e]] = (int32_t)lo;
+    }
+}
+
 }  // namespace
+
+int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int64_t n_rows, int64_t n_edges, hipStream_t s) {
+    if (n_edges <= 0) return 0;
+    const int64_t blocks = std::min<int64_t>((n_edges + 255) / 256, 65536);
+    hipLaunchKernelGGL(csc_dst_kernel, dim3((unsigned)blocks), dim3(256), 0, s, row_ptr, pos, cdst, n_rows, n_edges);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int HD, int N>
+static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const float* a,
+                    float slope, float* gPL, int64_t n_table, const int4* chunks, int32_t n_chunks, const int4* heavy,
+                    int32_t n_heavy, float* part, int wpb, hipStream_t s) {
+    if (n_heavy > 0) {                                  // long lists first: they are the longest-running waves
+        hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
+                           stash, cdst, gfull, a, slope, part);
+        const int64_t threads = (int64_t)n_heavy * HD;
+        hipLaunchKernelGGL(gpl_heavy_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, heavy, n_heavy, part, gPL, HD);
+    }
+    hipLaunchKernelGGL((gpl_pull_kernel<HD, N>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
+                       cdst, gfull, a, slope, gPL, n_table, heavy_slots());
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const float* a,
+                    float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
+                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, hipStream_t s) {
+    (void)n_slots;
+    if (n_table <= 0) return 0;
+    static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
+    const int HD = H * D;
+#define PULL(HD_, N_) return run_pull<HD_, N_>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, s)
+    if (D == 8 && HD == 64) PULL(64, 4);
+    if (D == 8 && HD == 32) PULL(32, 4);
+    if (D == 4 && HD == 64) PULL(64, 2);
+    if (D == 4 && HD == 32) PULL(32, 2);
+    if (D == 4 && HD == 16) PULL(16, 2);
+    if (D == 4 && HD == 8) PULL(8, 2);
+#undef PULL
+    return fail(GAT_E_UNSUPPORTED, "gpl_pull: no stash path for this (H, D)");
+}
 
 int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t* pos, int32_t* src_ptr,
               hipStream_t s) {

@@ -675,7 +675,10 @@ __global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
     }
 }
 
-template <int HD, int D, int N, int UU, int DBG, bool BF>
+// STASH (see edge_bwd2_kernel): instead of the H*D-float message row an edge leaves a record of H*D/N words in its
+// source-major slot — per head alpha and grad_attn_score, with the N LeakyReLU' decisions of the lane's channels in
+// the N low mantissa bits of the word (value rounded to nearest at that precision: relative 2^-(24-N)).
+template <int HD, int D, int N, int UU, int DBG, bool BF, bool STASH>
 __device__ __forceinline__ void bwd2_chunk(const EdgeBwdArgs& A, int e0, int e_end, int e_end_v, int cp, int gidx,
                                            int srcv, int posv, vnf<N> g, vnf<N> pr, float dot, vnf<N> ac, vnf<N> acs,
                                            vnf<N> ac2, float m2, float inv, vnf<N>& ga, vnf<N>& gpr) {
@@ -690,9 +693,10 @@ __device__ __forceinline__ void bwd2_chunk(const EdgeBwdArgs& A, int e0, int e_e
 #pragma unroll
     for (int u = 0; u < UU; ++u) {
         v[u] = gather_row_n<HD, N, BF>(A.PL, __shfl(srcv, u * G + gidx), cp);
-        sid[u] = __shfl(posv, u * G + gidx);
+        if constexpr (!STASH) sid[u] = __shfl(posv, u * G + gidx);     // STASH: fetched at the store (16 fewer live VGPRs: 4 waves/SIMD)
     }
-    constexpr int P = UU > 8 ? 8 : UU;
+    constexpr int PMAX = STASH ? 4 : 8;      // slots per compute pass (STASH: 4 keeps the kernel at 128 VGPRs = 4 waves/SIMD)
+    constexpr int P = UU > PMAX ? PMAX : UU;
 #pragma unroll
     for (int p0 = 0; p0 < UU; p0 += P) {
         float al[P], ga_[P];
@@ -715,14 +719,29 @@ __device__ __forceinline__ void bwd2_chunk(const EdgeBwdArgs& A, int e0, int e_e
             const vnf<N> gs = ge * select_pos<N>(s, ac, acs);        // ge * a * LReLU'(s)
             ga += ge * lrelu_n<N>(s, A.slope);
             gpr += gs;
-            const vnf<N> msg = g * al[q] + gs;                       // d/dPL[src] from this edge
-            if (valid && DBG != 1) store_row_n<HD, N, BF>(A.msg, sid[u], cp, msg);
+            if constexpr (STASH) {
+                static_assert(D / N == 2, "stash records: two lanes per head (one carries alpha, the other ge)");
+                uint32_t bits = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) bits |= (s[i] > 0.f ? 1u : 0u) << i;
+                const uint32_t w = __builtin_bit_cast(uint32_t, (cp & 1) ? ge : al[q]);
+                const uint32_t word = ((w + (1u << (N - 1))) & ~((1u << N) - 1u)) | bits;
+                const uint32_t slot = (uint32_t)__shfl(posv, u * G + gidx);
+                if (valid) A.stash[(uint64_t)slot * LPE + cp] = word;
+            } else {
+                const vnf<N> msg = g * al[q] + gs;                   // d/dPL[src] from this edge
+                if (valid && DBG != 1) store_row_n<HD, N, BF>(A.msg, sid[u], cp, msg);
+            }
         }
     }
 }
 
-template <int HD, int D, int N, int DBG = 0, bool BF = false>
-__global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) {
+// STASH = true is the training path wherever D/N == 2 (D = 8 with four channels per lane, D = 4 with two): the
+// per-edge record is H*D/N words (64 B at H*D = 64) instead of the H*D*4-byte message row, and gpl_pull_kernel
+// (gat_csc.hip) rebuilds each message from the record and ONE gathered row of g[dst] while it sums per source.
+// This kernel then also writes g[row] (dL/dh_pre with the LeakyReLU' factor applied) for that gather.
+template <int HD, int D, int N, int DBG, bool BF, bool STASH>
+__device__ __forceinline__ void edge_bwd2_body(const EdgeBwdArgs& A) {
     constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
     constexpr int U = 16 / G;
     constexpr int CH = 16;
@@ -759,6 +778,9 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) {
         const float m2 = A.mstat[row * H + c / D];
         const float inv = __builtin_amdgcn_rcpf(A.zstat[row * H + c / D] + 1e-8f);
         vnf<N> gpr = vzero<N>();
+        if constexpr (STASH) {                                       // one writer per row: whole rows, or a split row's first segment
+            if (gidx == 0 && (slot < 0 || b == A.row_ptr[row])) *reinterpret_cast<vnf<N>*>(A.gfull + row * HD + c) = g;
+        }
         // edge indices of a chunk: lane k < 16 holds edge e0+k (clamped into the item: no predicate needed)
         auto load_idx = [&](int e0, int& srcv, int& posv) {
             const int jl = e0 + (lane & (CH - 1));
@@ -772,10 +794,10 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) {
             int srcn = 0, posn = 0;
             if (e0 + CH < e_end) load_idx(e0 + CH, srcn, posn);      // next chunk's indices: in flight during this one
             if constexpr (U >= 2) {
-                if (e_end - e0 <= CH / 2) bwd2_chunk<HD, D, N, U / 2, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
-                else bwd2_chunk<HD, D, N, U, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
+                if (e_end - e0 <= CH / 2) bwd2_chunk<HD, D, N, U / 2, DBG, BF, STASH>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
+                else bwd2_chunk<HD, D, N, U, DBG, BF, STASH>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
             } else {
-                bwd2_chunk<HD, D, N, U, DBG, BF>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
+                bwd2_chunk<HD, D, N, U, DBG, BF, STASH>(A, e0, e_end, e_end_v, cp, gidx, srcv, posv, g, pr, dot, ac, acs, ac2, m2, inv, ga, gpr);
             }
             srcv = srcn; posv = posn;
         }
@@ -796,6 +818,14 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) {
     if (threadIdx.x < HD)
         A.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <int HD, int D, int N, int DBG = 0, bool BF = false, bool STASH = false>
+__global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) { edge_bwd2_body<HD, D, N, DBG, BF, STASH>(A); }
+// The stash variant sits a few registers above 128 VGPRs when left alone (3 waves/SIMD); it is told to fit 4 waves.
+template <int HD, int D, int N>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void edge_bwd2s_kernel(EdgeBwdArgs A) {
+    edge_bwd2_body<HD, D, N, 0, false, true>(A);
 }
 
 // gPR of split rows: sum of the row's segment partials in segment order (one thread per channel).
@@ -1009,9 +1039,14 @@ static int resident_blocks(const void* fn) {
     return cache[fn] = per_cu * (cus > 0 ? cus : 256);
 }
 static bool packed_backward() { return packed_layout(); }
-struct BwdSel { bool store, taps, bf16; };
+struct BwdSel { bool store, taps, bf16, stash; };
+// channels per lane of the stash variant of edge_bwd2_kernel for this shape (two lanes per head), 0 = none
+template <int HD, int D> constexpr int stash_n() { return (D == 8 && HD >= 32) ? 4 : (D == 4 ? 2 : 0); }
 template <int HD, int D, bool BF>
-const void* bwd_variant(bool store, bool taps) {
+const void* bwd_variant(bool store, bool taps, bool stash = false) {
+    if constexpr (stash_n<HD, D>() != 0 && !BF) {
+        if (stash && !taps) return (const void*)edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>;
+    }
     if constexpr (D % 2 == 0) {
         if (store && !taps && packed_backward()) {
             if constexpr (HD >= 32 && D % 4 == 0) {
@@ -1025,7 +1060,7 @@ const void* bwd_variant(bool store, bool taps) {
 }
 template <int HD, int D>
 int bwd_resident(const BwdSel& sel, hipStream_t) {
-    return resident_blocks(sel.bf16 ? bwd_variant<HD, D, true>(sel.store, sel.taps) : bwd_variant<HD, D, false>(sel.store, sel.taps));
+    return resident_blocks(sel.bf16 ? bwd_variant<HD, D, true>(sel.store, sel.taps) : bwd_variant<HD, D, false>(sel.store, sel.taps, sel.stash));
 }
 
 template <int HD, int D>
@@ -1038,8 +1073,15 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
         if (store && !taps && a.dbg == 2) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 2>), grid, block, 0, s, a); return 0; }
     }
     bool launched = false;
+    if constexpr (stash_n<HD, D>() != 0) {
+        if (a.stash != nullptr && !taps && !a.bf16) {
+            if (a.gfull == nullptr || a.pos == nullptr) return fail(GAT_E_INVALID, "edge_backward: stash path needs gfull and pos");
+            hipLaunchKernelGGL((edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
+            launched = true;
+        }
+    }
     if constexpr (D % 2 == 0) {
-        if (store && !taps && packed_backward()) {
+        if (!launched && store && !taps && packed_backward()) {
             bool four = false;
             if constexpr (HD >= 32 && D % 4 == 0) {
                 if (lane_channels() == 4) {
@@ -1110,11 +1152,23 @@ int launch_edge_forward(const EdgeFwdArgs& a, hipStream_t s) {
     return 0;
 }
 
-int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D_, bool store, bool taps, bool bf16) {
+template <int HD, int D>
+int stash_words_t(const int&, hipStream_t) { return stash_n<HD, D>() ? HD / stash_n<HD, D>() : 0; }
+int edge_stash_words(int32_t H, int32_t D_) {
+    const int HD = H * D_, D = D_;
+    const int dummy = 0;
+    auto probe = [&]() -> int {
+        GAT_DISPATCH_HD_D(stash_words_t, dummy, nullptr)
+        return 0;
+    };
+    return probe();
+}
+
+int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D_, bool store, bool taps, bool bf16, bool stash) {
     int64_t want = (n_items + 3) / 4;
     if (want < 1) want = 1;
     const int HD = H * D_, D = D_;
-    const BwdSel sel{store, taps, bf16};
+    const BwdSel sel{store, taps, bf16, stash};
     auto cap = [&]() -> int {
         GAT_DISPATCH_HD_D(bwd_resident, sel, nullptr)
         return 2048;                                  // generic path: one wave per block

@@ -90,6 +90,8 @@ struct EdgeBwdArgs {
     float* gPL;               // [n_table][HD]  atomics path only: zeroed by the caller, added into
     const int32_t* pos;       // [E] CSC slot of every edge, or null = atomics path
     float* msg;               // [E][HD] message rows by slot (store path; summed by launch_gpl_sum)
+    uint32_t* stash;          // or: [E][HD/N] per-edge records by slot (stash path, see edge_stash_words; launch_gpl_pull)
+    float* gfull;             // [n_rows][HD] written with the stash path: dL/dh_pre incl. the LReLU' factor (gathered by launch_gpl_pull)
     float* gPR;               // [n_rows][HD]   written
     float* ge;                // [E][H] or null (tap)
     float* galpha;            // [E][H] or null (tap, E:646); only with ge
@@ -109,8 +111,11 @@ struct EdgeBwdArgs {
     int32_t dbg;
 };
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s);
+// Words per edge record of the stash path for an (H, D) layer, 0 = that shape has no stash path (the message-row
+// path is used): two lanes per head are needed (D = 8 with four channels per lane, D = 4 with two).
+int edge_stash_words(int32_t H, int32_t D);
 // Grid size (== rows of ga_partial) for the backward of an (H, D) layer over n_items work items.
-int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D, bool store, bool taps, bool bf16);
+int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D, bool store, bool taps, bool bf16, bool stash = false);
 // wave-per-row templates cover this (H, D), and the gathered table is < 4 GiB (they address it as
 // uniform base + 32-bit byte offset); anything else runs the generic kernels
 bool edge_fast_path(int32_t H, int32_t D, int64_t n_table);
@@ -127,6 +132,12 @@ int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, HeavyList* out, 
 int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
                    int32_t HD, bool msg_bf16, const int4* chunks, int32_t n_chunks, const int4* heavy,
                    int32_t n_heavy, float* part, hipStream_t s);
+// cdst[pos[e]] = destination row of CSR edge e (the source-major twin of a1's dst array; built once per graph)
+int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int64_t n_rows, int64_t n_edges, hipStream_t s);
+// Stash path: gPL[s][:] = sum over the slots of s of  g[cdst][:] * alpha + ge * a (.) LReLU'  rebuilt from the records
+int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const float* a,
+                    float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
+                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, hipStream_t s);
 
 int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);

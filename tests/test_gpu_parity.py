@@ -360,8 +360,10 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
             ctx.close()
 
 
-@pytest.mark.parametrize("env", [{"GAT_PACKED": "0"}, {"GAT_CPL": "2"}, {"GAT_BWD_ATOMICS": "1"},
-                                 {"GAT_FWD_WAVES": "4", "GAT_GPL_WAVES": "1", "GAT_SEG_EDGES": "64"}])
+@pytest.mark.parametrize("env", [{"GAT_PACKED": "0", "GAT_BWD_STASH": "0"}, {"GAT_CPL": "2", "GAT_BWD_STASH": "0"},
+                                 {"GAT_BWD_STASH": "0"}, {"GAT_BWD_ATOMICS": "1"},
+                                 {"GAT_FWD_WAVES": "4", "GAT_GPL_WAVES": "1", "GAT_SEG_EDGES": "64"},
+                                 {"GAT_GPL_HEAVY": "64"}])
 def test_ab_switches_stay_correct(pkg, orc, env):
     """The A/B switches of DESIGN §7 select other kernels / launch shapes for the SAME math: each must still
     match the oracle (they are read once per process, hence a subprocess)."""
