@@ -253,7 +253,7 @@ static int ensure_buffers(gat_ctx* c) {
     const char* force = getenv("GAT_BWD_ATOMICS");
     if ((msg_hd > 0 || stash_words > 0) && E > 0 && !(force && force[0] == '1')) {
         float* m = nullptr;
-        if (hipMalloc((void**)&m, std::max<size_t>((size_t)E * msg_hd * (size_t)st_bytes(c), (size_t)E * stash_words * sizeof(uint32_t))) == hipSuccess) {
+        if (hipMalloc((void**)&m, std::max<size_t>((size_t)E * msg_hd * (size_t)st_bytes(c), (size_t)(E + 1) * stash_words * sizeof(uint32_t))) == hipSuccess) {
             c->owned.push_back(m);
             if (msg_hd > 0) { c->msg = m; c->msg_hd = msg_hd; }
             if (stash_words > 0) {                  // records and message rows are never live at the same time: one buffer
@@ -667,7 +667,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.g_raw = l < c->cfg.num_layers - 1;           // hidden layers: written by launch_grad_x without the LReLU' factor
     a.gh = (l == c->cfg.num_layers - 1) ? c->gH : nullptr;
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
-    a.stash = stash ? c->stash : nullptr; a.gfull = stash ? c->gfull : nullptr;
+    a.stash = stash ? c->stash : nullptr; a.gfull = stash ? c->gfull : nullptr; a.stash_spare = (uint32_t)c->n_edges;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots; a.n_split = c->work.n_split;
     a.part_acc = c->part_acc;
     a.dbg = c->dbg;

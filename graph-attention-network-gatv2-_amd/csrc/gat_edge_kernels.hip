@@ -700,6 +700,11 @@ __device__ __forceinline__ void bwd2_chunk(const EdgeBwdArgs& A, int e0, int e_e
 #pragma unroll
     for (int p0 = 0; p0 < UU; p0 += P) {
         float al[P], ga_[P];
+        [[maybe_unused]] uint32_t slots[P];
+        if constexpr (STASH) {                       // the pass's record slots, fetched together ahead of their use
+#pragma unroll
+            for (int q = 0; q < P; ++q) slots[q] = DBG == 2 ? (uint32_t)(e0 + (p0 + q) * G + gidx) : (uint32_t)__shfl(posv, (p0 + q) * G + gidx);
+        }
 #pragma unroll
         for (int q = 0; q < P; ++q) al[q] = hsum<N>(ac2 * lrelu_n<N>(v[p0 + q] + pr, A.slope));
         group_sum_n<DL, P>(al);
@@ -726,8 +731,10 @@ __device__ __forceinline__ void bwd2_chunk(const EdgeBwdArgs& A, int e0, int e_e
                 for (int i = 0; i < N; ++i) bits |= (s[i] > 0.f ? 1u : 0u) << i;
                 const uint32_t w = __builtin_bit_cast(uint32_t, (cp & 1) ? ge : al[q]);
                 const uint32_t word = ((w + (1u << (N - 1))) & ~((1u << N) - 1u)) | bits;
-                const uint32_t slot = (uint32_t)__shfl(posv, u * G + gidx);
-                if (valid) A.stash[(uint64_t)slot * LPE + cp] = word;
+                // straight-line: padded lanes write the spare record behind the last slot instead of being masked off
+                // (an exec-masked store is a branch, and hipcc drains the memory counters at its join point)
+                const uint32_t slot = valid ? slots[q] : A.stash_spare;
+                if constexpr (DBG != 1) A.stash[(uint64_t)slot * LPE + cp] = word;
             } else {
                 const vnf<N> msg = g * al[q] + gs;                   // d/dPL[src] from this edge
                 if (valid && DBG != 1) store_row_n<HD, N, BF>(A.msg, sid[u], cp, msg);
@@ -823,9 +830,9 @@ __device__ __forceinline__ void edge_bwd2_body(const EdgeBwdArgs& A) {
 template <int HD, int D, int N, int DBG = 0, bool BF = false, bool STASH = false>
 __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdArgs A) { edge_bwd2_body<HD, D, N, DBG, BF, STASH>(A); }
 // The stash variant sits a few registers above 128 VGPRs when left alone (3 waves/SIMD); it is told to fit 4 waves.
-template <int HD, int D, int N>
+template <int HD, int D, int N, int DBG = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void edge_bwd2s_kernel(EdgeBwdArgs A) {
-    edge_bwd2_body<HD, D, N, 0, false, true>(A);
+    edge_bwd2_body<HD, D, N, DBG, false, true>(A);
 }
 
 // gPR of split rows: sum of the row's segment partials in segment order (one thread per channel).
@@ -1069,14 +1076,19 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)a.ga_blocks), block(256);
     const bool store = a.pos != nullptr && a.msg != nullptr, taps = a.ge != nullptr;
     if constexpr (HD == 64 && D == 8) {          // timing experiments (GAT_DBG=1: no message store, 2: sequential slots)
-        if (store && !taps && a.dbg == 1) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 1>), grid, block, 0, s, a); return 0; }
-        if (store && !taps && a.dbg == 2) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 2>), grid, block, 0, s, a); return 0; }
+        if (store && !taps && a.stash == nullptr && a.dbg == 1) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 1>), grid, block, 0, s, a); return 0; }
+        if (store && !taps && a.stash == nullptr && a.dbg == 2) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 2>), grid, block, 0, s, a); return 0; }
     }
     bool launched = false;
     if constexpr (stash_n<HD, D>() != 0) {
         if (a.stash != nullptr && !taps && !a.bf16) {
             if (a.gfull == nullptr || a.pos == nullptr) return fail(GAT_E_INVALID, "edge_backward: stash path needs gfull and pos");
-            hipLaunchKernelGGL((edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
+            bool dbg_done = false;
+            if constexpr (HD == 64 && D == 8) {      // timing experiments (GAT_DBG=1: no record store, 2: records in CSR order)
+                if (a.dbg == 1) { hipLaunchKernelGGL((edge_bwd2s_kernel<64, 8, 4, 1>), grid, block, 0, s, a); dbg_done = true; }
+                if (a.dbg == 2) { hipLaunchKernelGGL((edge_bwd2s_kernel<64, 8, 4, 2>), grid, block, 0, s, a); dbg_done = true; }
+            }
+            if (!dbg_done) hipLaunchKernelGGL((edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
             launched = true;
         }
     }

@@ -90,7 +90,8 @@ struct EdgeBwdArgs {
     float* gPL;               // [n_table][HD]  atomics path only: zeroed by the caller, added into
     const int32_t* pos;       // [E] CSC slot of every edge, or null = atomics path
     float* msg;               // [E][HD] message rows by slot (store path; summed by launch_gpl_sum)
-    uint32_t* stash;          // or: [E][HD/N] per-edge records by slot (stash path, see edge_stash_words; launch_gpl_pull)
+    uint32_t* stash;          // or: [E + 1][HD/N] per-edge records by slot (stash path, see edge_stash_words; launch_gpl_pull)
+    uint32_t stash_spare;     // index of the spare record behind the last slot (= E): where padded lanes store
     float* gfull;             // [n_rows][HD] written with the stash path: dL/dh_pre incl. the LReLU' factor (gathered by launch_gpl_pull)
     float* gPR;               // [n_rows][HD]   written
     float* ge;                // [E][H] or null (tap)
