@@ -58,11 +58,30 @@ void build_worklist(const int32_t* rp, int64_t n_rows, WorkList& w) {
             ++w.n_slots;
         }
     }
-    // pass 2: every other row is one item
-    for (int64_t r = 0; r < n_rows; ++r) {
-        const int32_t b = rp[r], e = rp[r + 1];
-        if (e - b > kSegEdges) continue;
-        w.items.insert(w.items.end(), {(int32_t)r, b, e, -1});
+    // pass 2: every other row is one item.  The group-per-row kernels put 64/(H*D/N) consecutive items side by side in
+    // one wave, each lane group walking its own row, so neighbours should be of (nearly) equal length: rows are sorted
+    // by in-degree, longest first (counting sort, row order kept inside a degree) — inside WINDOWS of consecutive
+    // rows, so that the list still walks the graph roughly in row order (the per-row reads and writes of PR / h_pre / g
+    // stay near each other).  GAT_SORT_WINDOW rows per window, 0 = one window over all rows; swept on the Products
+    // shape: 4096 and one window are within noise for the backward, 4096 is ~3 % better for the forward.
+    {
+        static const int64_t win_env = [] { const char* e = getenv("GAT_SORT_WINDOW"); return e ? atoll(e) : (int64_t)-1; }();
+        const int64_t win = win_env < 0 ? 4096 : (win_env == 0 ? n_rows : win_env);
+        std::vector<int64_t> cnt((size_t)kSegEdges + 2);
+        for (int64_t r0 = 0; r0 < n_rows; r0 += win) {
+            const int64_t r1 = std::min(n_rows, r0 + win);
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int64_t r = r0; r < r1; ++r) { const int32_t d = rp[r + 1] - rp[r]; if (d <= kSegEdges) ++cnt[(size_t)(kSegEdges - d) + 1]; }
+            for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+            const size_t base = w.items.size();
+            w.items.resize(base + 4 * (size_t)cnt.back());
+            for (int64_t r = r0; r < r1; ++r) {
+                const int32_t b = rp[r], e = rp[r + 1];
+                if (e - b > kSegEdges) continue;
+                int32_t* it = &w.items[base + 4 * (size_t)cnt[(size_t)(kSegEdges - (e - b))]++];
+                it[0] = (int32_t)r; it[1] = b; it[2] = e; it[3] = -1;
+            }
+        }
     }
     w.n_items = (int64_t)(w.items.size() / 4);
     w.n_split = (int32_t)firsts.size();                 // appended after the per-slot entries: one int4 per split row

@@ -675,6 +675,101 @@ __global__ __launch_bounds__(256) void edge_fwd2_kernel(EdgeFwdArgs A) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// GROUP-PER-ROW kernels (training path).  The in-degree law of the benchmark graphs has median 12 / mean 25:
+// with one wave per row, the per-row work (descriptor, PR / h_pre / g rows, softmax stats, the cross-group merge,
+// the output rows, and three dependent memory latencies) is paid per ~25 edges and was 38 % of the forward and
+// 42 % of the backward (tools/shape_probe.py: t = a*N + b*E).  Here a wave carries G = 64/(H*D/N) work items side
+// by side — one per lane group (16 lanes at H*D = 64) — so that every per-row instruction serves G rows, a
+// gather instruction still moves G rows of PL (one per group), and no cross-group merge exists.  The work list is
+// sorted by length (build_worklist), so the G neighbours finish together; the loop runs to the longest of them.
+// Same arithmetic per row as the chunked kernels with one edge group; split rows leave the same partials.
+// ------------------------------------------------------------------------------------------------
+template <int HD, int N>
+__device__ __forceinline__ int wave_max_over_groups(int v) {
+    constexpr int LPE = HD / N;
+#pragma unroll
+    for (int off = LPE; off < 64; off <<= 1) { const int o = __shfl_xor(v, off); v = v > o ? v : o; }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int HD, int D, int N, bool BF = false>
+__global__ __launch_bounds__(256) void edge_fwd3_kernel(EdgeFwdArgs A) {
+    constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
+    constexpr int U = 4;                             // edges per group and step: G*U gathers in flight per wave
+    static_assert(D % N == 0 && LPE >= U, "lane layout");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cp = lane % LPE, gidx = lane / LPE;
+    const int c = N * cp;                            // first of the lane's channels
+    const int64_t it = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * G + gidx;
+    int row = -1, b = 0, e = 0, slot = -1;           // group without an item (tail of the list): walks nothing, writes nothing
+    if (it < A.n_items) { const int4 item = A.items[it]; row = item.x; b = item.y; e = item.z; slot = item.w; }
+    const int64_t rowc = row < 0 ? 0 : row;          // clamped: loads need no predicate
+    const vnf<N> pr = *reinterpret_cast<const vnf<N>*>(A.PR + rowc * HD + c);
+    const vnf<N> ac2 = *reinterpret_cast<const vnf<N>*>(A.a + c) * kLog2e;
+    float m = -1e9f * kLog2e, Z = 0.f;               // E:336 seeds the max with -1e9f
+    vnf<N> acc = vzero<N>();
+    const int nst = wave_max_over_groups<HD, N>((e - b + U - 1) / U);
+    // the step's U edge indices of every group: lanes 0..U-1 of the group load them (clamped into the row, and to
+    // edge 0 for an empty row: col_idx always has at least one element), the owning lanes get them by shuffle
+    auto load_idx = [&](int st) {
+        int j = b + st * U + (cp & (U - 1));
+        j = j < e ? j : e - 1;
+        return A.col_idx[j > 0 ? j : 0];
+    };
+    int srcv = load_idx(0);
+    for (int st = 0; st < nst; ++st) {
+        const int srcn = load_idx(st + 1);           // next step's indices: in flight during this one
+        vnf<N> v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = gather_row_n<HD, N, BF>(A.PL, __shfl(srcv, gidx * LPE + u), cp);
+        float t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = hsum<N>(ac2 * lrelu_n<N>(v[u] + pr, A.slope));
+        group_sum_n<DL, U>(t);
+        float cm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            t[u] = (b + st * U + u < e) ? t[u] : -INFINITY;
+            cm = fmaxf(cm, t[u]);
+        }
+        const float mn = fmaxf(m, cm);
+        const float scale = exp2_fast(m - mn);
+        Z *= scale;
+        acc = acc * scale;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float p = exp2_fast(t[u] - mn);    // 0 for padded slots
+            Z += p;
+            acc += p * v[u];
+        }
+        m = mn;
+        srcv = srcn;
+    }
+    if (row < 0) return;
+    if (slot >= 0) {                                 // one segment of a long row: partial (m, Z, acc) -> edge_fwd_fix_kernel
+        *reinterpret_cast<vnf<N>*>(A.part_acc + (int64_t)slot * HD + c) = acc;
+        if ((c % D) == 0) {
+            A.part_mz[(int64_t)slot * 2 * H + c / D] = m;
+            A.part_mz[(int64_t)slot * 2 * H + H + c / D] = Z;
+        }
+        return;
+    }
+    const vnf<N> hp = acc * __builtin_amdgcn_rcpf(Z + 1e-8f);    // E:379 epsilon
+    *reinterpret_cast<vnf<N>*>(A.hpre + (int64_t)row * HD + c) = hp;
+    if ((c % D) == 0) { A.mstat[(int64_t)row * H + c / D] = m; A.zstat[(int64_t)row * H + c / D] = Z; }
+    const vnf<N> act = lrelu_n<N>(hp, A.slope);
+    if (!A.is_last) {
+        *reinterpret_cast<vnf<N>*>(A.hout + (int64_t)row * HD + c) = act;     // concat heads (E:452-457)
+    } else {
+        vnf<N> t = act;                              // activate, then average heads (E:440-449)
+#pragma unroll
+        for (int off = DL; off < LPE; off <<= 1) t += shfl_xor_n<N>(t, off);
+        if (cp < DL) *reinterpret_cast<vnf<N>*>(A.hout + (int64_t)row * D + c) = t / (float)H;
+    }
+}
+
 // STASH (see edge_bwd2_kernel): instead of the H*D-float message row an edge leaves a record of H*D/N words in its
 // source-major slot — per head alpha and grad_attn_score, with the N LeakyReLU' decisions of the lane's channels in
 // the N low mantissa bits of the word (value rounded to nearest at that precision: relative 2^-(24-N)).
@@ -835,6 +930,140 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     edge_bwd2_body<HD, D, N, DBG, false, true>(A);
 }
 
+// Group-per-row backward with per-edge records (see edge_fwd3_kernel and the STASH note at bwd2_chunk): persistent
+// waves take quads of G work items (static round-robin over the length-sorted list: every wave gets the same mix).
+template <int HD, int D, int N, int DBG = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void edge_bwd3_kernel(EdgeBwdArgs A) {
+    constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
+    constexpr int U = 4;
+    static_assert(DL == 2 && LPE >= U, "two lanes per head (one carries alpha, the other ge)");
+    __shared__ float red[4][HD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cp = lane % LPE, gidx = lane / LPE;
+    const int c = N * cp;
+    const vnf<N> ac = *reinterpret_cast<const vnf<N>*>(A.a + c);
+    const vnf<N> acs = ac * A.slope;
+    const vnf<N> ac2 = ac * kLog2e;
+    const int64_t nquads = (A.n_items + G - 1) / G;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    vnf<N> ga = vzero<N>();
+
+    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nquads; q += nwaves) {
+        const int64_t it = q * G + gidx;
+        int row = -1, b = 0, e = 0, slot = -1;       // group without an item: walks nothing, writes nothing
+        if (it < A.n_items) { const int4 item = A.items[it]; row = item.x; b = item.y; e = item.z; slot = item.w; }
+        const int64_t rowc = row < 0 ? 0 : row;      // clamped: loads need no predicate
+        // the step's U edge indices of the group: lanes 0..U-1 of the group load them (clamped into the row; an empty
+        // row reads edge 0: col_idx / pos always hold at least one element), the owning lanes get them by shuffle
+        auto load_idx = [&](int st, int& srcv, int& posv) {
+            int j = b + st * U + (cp & (U - 1));
+            j = j < e ? j : e - 1;
+            j = j > 0 ? j : 0;
+            srcv = A.col_idx[j];
+            posv = (DBG == 2) ? j : A.pos[j];
+        };
+        auto spread = [&](int st, int srcv, int posv, int (&src)[U], uint32_t (&sl)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                src[u] = __shfl(srcv, gidx * LPE + u);
+                const uint32_t p = (uint32_t)__shfl(posv, gidx * LPE + u);
+                sl[u] = (b + st * U + u < e) ? p : A.stash_spare;    // padded lanes store to the spare record (no exec-masked store)
+            }
+        };
+        int srcv, posv, srcn, posn;
+        load_idx(0, srcv, posv);
+        load_idx(1, srcn, posn);
+        const vnf<N> hp = *reinterpret_cast<const vnf<N>*>(A.hpre + rowc * HD + c);
+        vnf<N> dsel;
+#pragma unroll
+        for (int i = 0; i < N; ++i) dsel[i] = hp[i] > 0.f ? 1.0f : A.slope;
+        vnf<N> g;
+        if (A.gh != nullptr) g = *reinterpret_cast<const vnf<N>*>(A.gh + rowc * D + (c % D)) * dsel * (1.0f / (float)H);   // E:598-603
+        else {
+            g = *reinterpret_cast<const vnf<N>*>(A.g + rowc * HD + c);
+            if (A.g_raw) g = g * dsel;               // E:888-892 applied by the consumer
+        }
+        const vnf<N> pr = *reinterpret_cast<const vnf<N>*>(A.PR + rowc * HD + c);
+        const float dot = group_sum<DL>(hsum<N>(g * hp));
+        const float m2 = A.mstat[rowc * H + c / D];
+        const float inv = __builtin_amdgcn_rcpf(A.zstat[rowc * H + c / D] + 1e-8f);
+        if (row >= 0 && (slot < 0 || b == A.row_ptr[rowc]))      // one writer per row: whole rows, or a split row's first segment
+            *reinterpret_cast<vnf<N>*>(A.gfull + rowc * HD + c) = g;
+        vnf<N> gpr = vzero<N>();
+        const int nst = wave_max_over_groups<HD, N>((e - b + U - 1) / U);
+        // Software pipeline.  vmcnt retires loads AND stores in issue order, so a store issued ahead of a gather makes the
+        // gather's consumer wait for the store's acknowledgement as well (measured: without its record stores the kernel
+        // ran 2x faster, wherever the stores went).  Per step, in this order: gathers of the step; the PREVIOUS step's
+        // records; shuffles of the next step's indices (loaded two steps ago: older than everything above); index loads
+        // two steps ahead; only then the wait for the gathers, with the stores and index loads still in flight.
+        int src[U];
+        uint32_t sl[U], pend_s[U], pend_w[U];
+        spread(0, srcv, posv, src, sl);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { pend_w[u] = 0u; pend_s[u] = A.stash_spare; }
+        for (int st = 0; st < nst; ++st) {
+            vnf<N> v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = gather_row_n<HD, N, false>(A.PL, src[u], cp);
+            if constexpr (DBG == 3) {                // timing experiment: the step's bytes as ONE 16-B-per-lane store, CSR order
+                const int j0 = b + (st > 0 ? st - 1 : 0) * U;
+                uint4 w4 = make_uint4(pend_w[0], pend_w[1], pend_w[2], pend_w[3]);
+                *reinterpret_cast<uint4*>(A.stash + (uint64_t)(uint32_t)(j0 < e ? j0 : 0) * LPE + cp * 4) = w4;
+            } else if constexpr (DBG != 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) A.stash[(uint64_t)pend_s[u] * LPE + cp] = pend_w[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) pend_s[u] = sl[u];
+            spread(st + 1, srcn, posn, src, sl);
+            load_idx(st + 2, srcn, posn);
+            float al[U], ga_[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) al[u] = hsum<N>(ac2 * lrelu_n<N>(v[u] + pr, A.slope));
+            group_sum_n<DL, U>(al);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                al[u] = exp2_fast(al[u] - m2) * inv;
+                ga_[u] = hsum<N>(g * v[u]);
+            }
+            group_sum_n<DL, U>(ga_);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool valid = b + st * U + u < e;
+                const float ge = valid ? al[u] * (ga_[u] - dot) : 0.f;   // padded slots contribute nothing
+                const vnf<N> s = v[u] + pr;
+                const vnf<N> gs = ge * select_pos<N>(s, ac, acs);        // ge * a * LReLU'(s)
+                ga += ge * lrelu_n<N>(s, A.slope);
+                gpr += gs;
+                uint32_t bits = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) bits |= (s[i] > 0.f ? 1u : 0u) << i;
+                const uint32_t w = __builtin_bit_cast(uint32_t, (cp & 1) ? ge : al[u]);
+                pend_w[u] = ((w + (1u << (N - 1))) & ~((1u << N) - 1u)) | bits;
+            }
+        }
+        if constexpr (DBG != 1 && DBG != 3) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) A.stash[(uint64_t)pend_s[u] * LPE + cp] = pend_w[u];         // the last step's records
+        }
+        if (row >= 0) {
+            float* dst = slot < 0 ? A.gPR + rowc * HD + c : A.part_acc + (int64_t)slot * HD + c;   // segment partial -> fix kernel
+            *reinterpret_cast<vnf<N>*>(dst) = gpr;
+        }
+    }
+#pragma unroll
+    for (int off = LPE; off < 64; off <<= 1) ga += shfl_xor_n<N>(ga, off);
+    if (gidx == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[wave][c + i] = ga[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < HD)
+        A.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // gPR of split rows: sum of the row's segment partials in segment order (one thread per channel).
 __global__ __launch_bounds__(256) void edge_bwd_fix_kernel(const int4* __restrict__ slot_info, int32_t n_slots,
                                                           int32_t n_split, const float* __restrict__ part,
@@ -974,6 +1203,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// channels per lane of the two-lanes-per-head kernels (stash backward, group-per-row kernels) for this shape, 0 = none
+template <int HD, int D> constexpr int stash_n() { return (D == 8 && HD >= 32) ? 4 : (D == 4 ? 2 : 0); }
+// GAT_ROWGROUP=0: one wave per row (chunked kernels) instead of one lane group per row (A/B)
+static bool row_groups() {
+    static const bool v = [] { const char* e = getenv("GAT_ROWGROUP"); return !(e && e[0] == '0'); }();
+    return v;
+}
 // GAT_PACKED=0 keeps the one-channel-per-lane kernels on the training path too (A/B)
 static bool packed_layout() {
     static const bool v = [] { const char* e = getenv("GAT_PACKED"); return !(e && e[0] == '0'); }();
@@ -1004,6 +1240,17 @@ int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
                 // 10-edge rows) and pins the other three wave slots meanwhile — 5.51 -> 5.02 ms per step
                 static const int wpb = [] { const char* e = getenv("GAT_FWD_WAVES"); const int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
                 const dim3 grid((unsigned)((a.n_items + wpb - 1) / wpb)), block(64 * wpb);
+                if constexpr (stash_n<HD, D>() != 0) {        // group-per-row kernel (GAT_ROWGROUP=0: the chunked one, A/B)
+                    if (row_groups()) {
+                        constexpr int NN = stash_n<HD, D>(), GG = 64 / (HD / NN);
+                        const dim3 g3((unsigned)((a.n_items + (int64_t)GG * wpb - 1) / ((int64_t)GG * wpb)));
+                        if (a.bf16) hipLaunchKernelGGL((edge_fwd3_kernel<HD, D, NN, true>), g3, block, 0, s, a);
+                        else hipLaunchKernelGGL((edge_fwd3_kernel<HD, D, NN, false>), g3, block, 0, s, a);
+                        if (a.n_slots > 0) hipLaunchKernelGGL((edge_fwd_fix_kernel<HD, D, false>), fgrid, dim3(256), 0, s, a);
+                        GAT_HIP(hipGetLastError());
+                        return 0;
+                    }
+                }
                 bool four = false;
                 if constexpr (HD >= 32 && D % 4 == 0) {
                     if (lane_channels() == 4) {
@@ -1047,12 +1294,11 @@ static int resident_blocks(const void* fn) {
 }
 static bool packed_backward() { return packed_layout(); }
 struct BwdSel { bool store, taps, bf16, stash; };
-// channels per lane of the stash variant of edge_bwd2_kernel for this shape (two lanes per head), 0 = none
-template <int HD, int D> constexpr int stash_n() { return (D == 8 && HD >= 32) ? 4 : (D == 4 ? 2 : 0); }
 template <int HD, int D, bool BF>
 const void* bwd_variant(bool store, bool taps, bool stash = false) {
     if constexpr (stash_n<HD, D>() != 0 && !BF) {
-        if (stash && !taps) return (const void*)edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>;
+        if (stash && !taps) return row_groups() ? (const void*)edge_bwd3_kernel<HD, D, stash_n<HD, D>()>
+                                                : (const void*)edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>;
     }
     if constexpr (D % 2 == 0) {
         if (store && !taps && packed_backward()) {
@@ -1085,10 +1331,16 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
             if (a.gfull == nullptr || a.pos == nullptr) return fail(GAT_E_INVALID, "edge_backward: stash path needs gfull and pos");
             bool dbg_done = false;
             if constexpr (HD == 64 && D == 8) {      // timing experiments (GAT_DBG=1: no record store, 2: records in CSR order)
-                if (a.dbg == 1) { hipLaunchKernelGGL((edge_bwd2s_kernel<64, 8, 4, 1>), grid, block, 0, s, a); dbg_done = true; }
-                if (a.dbg == 2) { hipLaunchKernelGGL((edge_bwd2s_kernel<64, 8, 4, 2>), grid, block, 0, s, a); dbg_done = true; }
+                if (a.dbg == 3 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 3>), grid, block, 0, s, a); dbg_done = true; }
+                else if (a.dbg == 1 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 1>), grid, block, 0, s, a); dbg_done = true; }
+                else if (a.dbg == 2 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 2>), grid, block, 0, s, a); dbg_done = true; }
+                else if (a.dbg == 1) { hipLaunchKernelGGL((edge_bwd2s_kernel<64, 8, 4, 1>), grid, block, 0, s, a); dbg_done = true; }
+                else if (a.dbg == 2) { hipLaunchKernelGGL((edge_bwd2s_kernel<64, 8, 4, 2>), grid, block, 0, s, a); dbg_done = true; }
             }
-            if (!dbg_done) hipLaunchKernelGGL((edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
+            if (!dbg_done) {
+                if (row_groups()) hipLaunchKernelGGL((edge_bwd3_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
+            }
             launched = true;
         }
     }
