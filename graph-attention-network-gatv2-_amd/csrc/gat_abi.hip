@@ -1249,7 +1249,10 @@ int gat_algorithmic_bytes_shape(const gat_config* cfg, int64_t n_rows, int64_t n
         const double NL = (l == 0 && replicated_input) ? (double)n_table : N;     // rows of the W_left half (shards)
         k[GAT_K_PROJECT] += b * (std::max(N, NL) * F + 2 * HD * F + (N + NL) * HD);          // X, W read; PL + PR written
         k[GAT_K_EDGE_FWD] += 4 * (N + 1) + 4 * E + b * (E * HD + N * HD + E * H + N * HD + N * Dout);   // PL[src], PR, alpha, h_pre, H
-        k[GAT_K_EDGE_BWD] += 4 * (N + 1) + 4 * E + b * (N * HD + E * HD + N * HD + E * H + E * HD + N * HD);   // g, PL[src], PR, alpha, gPL scatter, gPR
+        // g, PL[src], PR, alpha, gPR in the destination-major pass; the gPL scatter (counted once, E*HD) belongs to the
+        // source-major pass that performs it here (it gathers g[dst] per edge and sums per source)
+        k[GAT_K_EDGE_BWD] += 4 * (N + 1) + 4 * E + b * (N * HD + E * HD + N * HD + E * H + N * HD);
+        k[GAT_K_GPL_SUM] += b * E * HD;
         k[GAT_K_GRAD_W] += b * ((N + NL) * HD + std::max(N, NL) * F + 2 * HD * F);            // gPL + gPR re-read, X, grad_W
         if (l > 0) k[GAT_K_GRAD_X] += b * (2 * N * HD + 2 * N * F);                            // gPL + gPR, gX write, h_pre_{l-1}
     }

@@ -12,7 +12,8 @@ import collections, csv, glob, json, re, sys
 
 CLASSES = [("edge_bwd", "edge_backward"), ("edge_fwd", "edge_forward"), ("gpl_", "gpl_sum"),
            ("gradw_kernel", "grad_w_gemm"), ("EpiProject", "project_gemm"), ("EpiGradX", "grad_x_gemm"),
-           ("EpiStore", "grad_x_gemm"), ("head_forward_kernel", "head_forward"), ("head_backward_kernel", "head_backward")]
+           ("EpiStore", "grad_x_gemm"), ("head_forward_kernel", "head_forward"), ("head_backward_kernel", "head_backward"),
+           ("head_step_kernel", "head_backward")]
 
 
 def load(d):
@@ -45,7 +46,15 @@ def main(src, dst):
         nw = max(1, len(wdisp[cls]))
         out["kernels"][cls] = {"read_bytes": reads / n, "write_bytes": writes / nw, "launches_counted": n,
                                "bytes_per_launch": reads / n + writes / nw}
+    # the passes run `bench.py --steps 2 --warmup 1`: 3 steps => launches per step, and the step's total HBM traffic
+    steps = 3
+    tot = 0.0
+    for cls, v in out["kernels"].items():
+        v["launches_per_step"] = v["launches_counted"] / steps
+        tot += v["bytes_per_launch"] * v["launches_per_step"]
+    out["bytes_per_step"] = tot
     json.dump(out, open(dst, "w"), indent=1)
+    print(f"step total {out['bytes_per_step'] / 1e9:.2f} GB")
     for k, v in out["kernels"].items():
         print(f"{k:16s} {v['bytes_per_launch'] / 1e9:8.3f} GB/launch  (R {v['read_bytes'] / 1e9:.3f} + W {v['write_bytes'] / 1e9:.3f}, n={v['launches_counted']})")
 
