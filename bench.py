@@ -186,8 +186,11 @@ def main():
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world, **kw)
 
     # ---- synthetic inputs (same on every rank; each keeps its destination range) ----
+    # generated ON the device (csrc/gat_synth.hip; bit-for-bit the host generator's arrays): the host only builds the
+    # N-sized tables.  N > 1: every rank draws the whole graph on its own GPU and keeps its destination range.
     t_gen = time.perf_counter()
-    row_ptr, col_idx = pkg.synth.powerlaw_graph(n, e, beta=args.beta)
+    dsd = pkg.synth.make_dataset_device(args.workload, dev, scale=args.scale, beta=args.beta)
+    row_ptr = dsd["row_ptr"]
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         use_graph = args.graph and world == 1 and os.environ.get("GAT_FORCE_SHARDED") != "1"
@@ -200,26 +203,28 @@ def main():
             dist.init_process_group(backend=args.backend, rank=0, world_size=1)
         t_up = 0.0
         if world == 1 and not force_sharded:
-            x_host, lab_host = pkg.synth.features(n, f, kind=kind), pkg.synth.labels(n, c)
             t_up = time.perf_counter()
-            ctx.set_graph(row_ptr, col_idx)          # host -> HBM once, + work list + source-major index
-            ctx.set_features(x_host)
-            ctx.set_labels(lab_host)
+            d_rp = torch.from_numpy(row_ptr).to(dev)
+            ctx.set_graph_device(d_rp.data_ptr(), dsd["d_col_idx"].data_ptr(), n, e)      # + work list + source-major index
+            ctx.set_features_device(dsd["d_x"].data_ptr(), n, f)
+            ctx.set_labels_device(dsd["d_labels"].data_ptr(), n)
             ctx.sync()
             t_up = time.perf_counter() - t_up
-            del x_host, lab_host
+            del d_rp
             runner = None
         else:
+            col_idx = dsd["d_col_idx"].cpu().numpy()
             S = pkg.shard
             plan = S.make_plan(row_ptr, world, rank)
             rp_l, ci_l = S.local_csr(plan, row_ptr, col_idx)
             lo, hi = plan.row0, plan.row0 + plan.n_rows
             ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
             if args.exchange_layer0:     # A/B: exchange layer 0 like the hidden layers
-                ctx.set_features(pkg.synth.features(n, f, rows=(lo, hi), kind=kind))
+                ctx.set_features_device(dsd["d_x"][lo:hi].contiguous().data_ptr(), hi - lo, f)
             else:                        # static input replicated on every rank: layer 0 runs without exchanges
-                ctx.set_source_features(plan.table_features(pkg.synth.features(n, f, kind=kind)))
-            ctx.set_labels(pkg.synth.labels(n, c, rows=(lo, hi)))
+                ctx.set_source_features(plan.table_features(dsd["d_x"].cpu().numpy()))
+            ctx.set_labels_device(dsd["d_labels"][lo:hi].contiguous().data_ptr(), hi - lo)
+            del col_idx
             comm_kind = args.comm if args.backend == "nccl" else "torch"
             if comm_kind == "native":
                 # the library's own RCCL communicator; torch.distributed only ships the 128-byte id
@@ -232,7 +237,8 @@ def main():
             else:
                 runner = S.ShardedGat(ctx, plan, S.TorchComm(), heads, outdims,
                                       alloc=lambda k: torch.empty(k, dtype=torch.float32, device=dev))
-        del row_ptr, col_idx
+        del row_ptr, dsd
+        torch.cuda.empty_cache()
         ctx.params_init(42)
         ctx.zero_grad()
         t_gen = time.perf_counter() - t_gen
@@ -313,7 +319,8 @@ def main():
                 "parallelism": (f"dst-range x{world}, " + ("all layers exchanged" if args.exchange_layer0 else
                                 "input features replicated (layer 0 exchange-free)") + f", exchanges: {comm_kind}")
                                if runner is not None else "single GPU",
-                "loss_per_node": loss / n, "setup_s": round(t_gen, 1), "upload_and_index_s": round(t_up, 2),
+                "loss_per_node": loss / n, "setup_s": round(t_gen, 1), "index_s": round(t_up, 2),
+                "generator": "device (csrc/gat_synth.hip), bit-for-bit synth.py",
             },
             "step_roofline": {"algorithmic_GB_per_step": bytes_step_all / 1e9,
                               "achieved_GBps": bytes_step_all / (dt / args.steps) / 1e9 / world,

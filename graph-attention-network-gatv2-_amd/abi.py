@@ -151,6 +151,10 @@ def _declare(lib: C.CDLL) -> None:
         "gat_kernel_stats_reset": [vp],
         "gat_algorithmic_bytes": [vp, P(C.c_double), P(C.c_double)],
         "gat_algorithmic_bytes_shape": [P(_Config), i64, i64, i64, i32, P(C.c_double), P(C.c_double)],
+        "gat_synth_sources_device": [vp, vp, vp, i64, i64, C.c_uint64, vp, vp],
+        "gat_synth_features_device": [C.c_uint64, i64, i64, i32, i32, vp, vp],
+        "gat_synth_labels_device": [C.c_uint64, i64, i64, i32, vp, vp],
+        "gat_synth_argsort_u64": [vp, i64, vp, vp],
     }
     for name, argt in sigs.items():
         fn = getattr(lib, name)          # AttributeError here == symbol missing from the .so

@@ -38,36 +38,52 @@ def _uniform01(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
     return (_hash(seed, stream, idx) >> _U64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
-def _perm(seed: int, stream: int, n: int) -> np.ndarray:
+def _argsort_u64(keys: np.ndarray) -> np.ndarray:
+    return np.argsort(keys, kind="stable")
+
+
+def _perm(seed: int, stream: int, n: int, argsort=_argsort_u64) -> np.ndarray:
     """pi[i] = rank of node i under a seeded hash order."""
-    order = np.argsort(_hash(seed, stream, np.arange(n, dtype=np.uint64)), kind="stable")
+    order = argsort(_hash(seed, stream, np.arange(n, dtype=np.uint64)))
     pi = np.empty(n, np.int64)
     pi[order] = np.arange(n, dtype=np.int64)
     return pi
 
 
-def powerlaw_graph(n: int, e: int, seed: int = GRAPH_SEED, beta: float = 0.75, r0: float = 100.0
-                   ) -> Tuple[np.ndarray, np.ndarray]:
-    """-> (row_ptr int32[n+1], col_idx int32[e])"""
+def graph_tables(n: int, e: int, seed: int = GRAPH_SEED, beta: float = 0.75, r0: float = 100.0, argsort=_argsort_u64):
+    """The N-sized part of the graph law: -> (row_ptr int32[n+1], cdf float64[n] over rank weights,
+    node_of_rank int32[n]).  Cheap (a few argsorts of n values); the E-sized part follows in powerlaw_graph (host)
+    or gat_synth_sources_device (GPU, same arrays bit for bit).  `argsort`: stable ascending argsort of uint64 keys
+    (the device generator passes one that sorts on the GPU)."""
     rank_w = (np.arange(n, dtype=np.float64) + r0) ** (-beta)        # weight by rank
-    pi_in = _perm(seed, 1, n)
+    pi_in = _perm(seed, 1, n, argsort)
     w = rank_w[pi_in]
     quota = w * (e / w.sum())
     deg = np.floor(quota).astype(np.int64)
     rem = int(e - deg.sum())
     if rem > 0:
         frac = quota - deg
-        top = np.argsort(-frac, kind="stable")[:rem]
+        # largest remainders first, ties in node order: == argsort(-frac, stable).  frac is in [0, 1): the bit
+        # patterns of non-negative doubles order like the values, their complements the other way round
+        top = argsort(~np.ascontiguousarray(frac).view(np.uint64))[:rem]
         deg[top] += 1
     row_ptr = np.zeros(n + 1, np.int64)
     np.cumsum(deg, out=row_ptr[1:])
     assert row_ptr[-1] == e
     # sources: inverse CDF over rank weights, rank -> node through an independent permutation
-    pi_src = _perm(seed, 2, n)
+    pi_src = _perm(seed, 2, n, argsort)
     node_of_rank = np.empty(n, np.int64)
     node_of_rank[pi_src] = np.arange(n, dtype=np.int64)
     cdf = np.cumsum(rank_w)
     cdf /= cdf[-1]
+    return row_ptr.astype(np.int32), cdf, node_of_rank.astype(np.int32)
+
+
+def powerlaw_graph(n: int, e: int, seed: int = GRAPH_SEED, beta: float = 0.75, r0: float = 100.0
+                   ) -> Tuple[np.ndarray, np.ndarray]:
+    """-> (row_ptr int32[n+1], col_idx int32[e])"""
+    row_ptr, cdf, node_of_rank = graph_tables(n, e, seed, beta, r0)
+    deg = np.diff(row_ptr.astype(np.int64))
     col = np.empty(e, np.int64)
     step = 1 << 24
     for lo in range(0, e, step):
@@ -81,7 +97,7 @@ def powerlaw_graph(n: int, e: int, seed: int = GRAPH_SEED, beta: float = 0.75, r
     key = dst * np.int64(n) + col
     key.sort(kind="stable")
     col = (key % np.int64(n)).astype(np.int32)
-    return row_ptr.astype(np.int32), col
+    return row_ptr, col
 
 
 def features(n: int, f: int, seed: int = GRAPH_SEED + 1, rows: Optional[Tuple[int, int]] = None,
@@ -129,6 +145,37 @@ def make_dataset(name: str, scale: float = 1.0, seed: int = GRAPH_SEED):
     rp, ci = powerlaw_graph(n, e, seed)
     return dict(row_ptr=rp, col_idx=ci, x=features(n, f, seed + 1, kind=kind), labels=labels(n, c, seed + 2),
                 n=n, e=e, f=f, c=c, name=name)
+
+
+def make_dataset_device(name: str, device, scale: float = 1.0, seed: int = GRAPH_SEED, stream: int = 0, beta: float = 0.75):
+    """The same dataset generated ON the GPU (csrc/gat_synth.hip): the host builds the N-sized tables, the device
+    draws and sorts the E sources and fills features and labels.  -> dict(row_ptr (host int32), d_col_idx, d_x,
+    d_labels (torch tensors on `device`: feed their data_ptr() to GatContext.set_*_device), n, e, f, c).  Bit-for-bit
+    make_dataset's arrays (tests/test_synth_device.py)."""
+    import ctypes as C
+    import torch
+    from . import abi
+    lib = abi.load_library()
+    n, e, f, c, kind = SHAPES[name]
+    if scale != 1.0:
+        n, e = max(16, int(n * scale)), max(16, int(e * scale))
+    def device_argsort(keys):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        order = np.empty(len(keys), np.int32)
+        abi._chk(lib.gat_synth_argsort_u64(keys.ctypes.data_as(C.c_void_p), len(keys), order.ctypes.data_as(C.c_void_p), None))
+        return order
+
+    rp, cdf, nor = graph_tables(n, e, seed, beta, argsort=device_argsort)
+    d_col = torch.empty(max(e, 1), dtype=torch.int32, device=device)
+    d_x = torch.empty((n, f), dtype=torch.float32, device=device)
+    d_lab = torch.empty(n, dtype=torch.int32, device=device)
+    st = C.c_void_p(stream or None)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    abi._chk(lib.gat_synth_sources_device(vp(cdf), vp(nor), vp(rp), n, e, seed, C.c_void_p(d_col.data_ptr()), st))
+    abi._chk(lib.gat_synth_features_device(seed + 1, 0, n, f, 1 if kind == "bow" else 0, C.c_void_p(d_x.data_ptr()), st))
+    abi._chk(lib.gat_synth_labels_device(seed + 2, 0, n, c, C.c_void_p(d_lab.data_ptr()), st))
+    torch.cuda.synchronize(device)
+    return dict(row_ptr=rp, d_col_idx=d_col[:e], d_x=d_x, d_labels=d_lab, n=n, e=e, f=f, c=c, name=name)
 
 
 def write_text_dataset(ds: dict, root: str, name: Optional[str] = None) -> str:

@@ -217,6 +217,25 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
                           const float* d_hpre_prev, float* d_g_prev, int64_t n, int64_t e,
                           int32_t f, int32_t h, int32_t d, float slope, void* stream);
 
+/* ---- synthetic workloads on the device --------------------------------------------
+ * The reference's datasets are a download link (README R:21); every BASELINE workload here is a deterministic
+ * synthetic graph of the stated shape (SURVEY 8d law; host implementation: synth.py).  These three calls do the
+ * parts proportional to E and N*F on the GPU, bit-for-bit equal to the host generator.  Outputs are DEVICE
+ * pointers (feed them to gat_set_*_device).  `stream` may be NULL.
+ *   sources : per edge e, u = hash(seed, 3, e) -> rank = first r with h_cdf[r] > u -> h_node_of_rank[rank]; the
+ *             sources of every row then sorted ascending (one radix sort of dst*n + src).  h_cdf / h_node_of_rank /
+ *             h_row_ptr are the host's N-sized tables (synth.graph_tables).
+ *   features: kind 0 = U[-1,1) fp32, kind 1 = sparse binary rows normalised by their count (Cora-like); rows
+ *             [row0, row0+rows) of the [n][f] matrix.
+ *   labels  : hash % num_classes, node 0 forced to num_classes-1.
+ *   argsort : the three N-sized stable sorts of the host tables (two node permutations, the largest-remainder order). */
+int gat_synth_sources_device(const double* h_cdf, const int32_t* h_node_of_rank, const int32_t* h_row_ptr, int64_t n,
+                             int64_t n_edges, uint64_t seed, int32_t* d_col_idx, void* stream);
+/* host keys -> host order, sorted on the device: order[i] = index of the i-th smallest key, ties in index order */
+int gat_synth_argsort_u64(const uint64_t* h_keys, int64_t n, int32_t* h_order, void* stream);
+int gat_synth_features_device(uint64_t seed, int64_t row0, int64_t rows, int32_t f, int32_t kind, float* d_x, void* stream);
+int gat_synth_labels_device(uint64_t seed, int64_t row0, int64_t rows, int32_t num_classes, int32_t* d_labels, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 enum {
     GAT_K_PROJECT = 0, GAT_K_EDGE_FWD = 1, GAT_K_HEAD_FWD = 2, GAT_K_HEAD_BWD = 3,
