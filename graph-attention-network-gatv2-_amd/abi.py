@@ -108,6 +108,8 @@ def _declare(lib: C.CDLL) -> None:
         "gat_set_graph": [vp, vp, vp, i64, i64, i64, i64],
         "gat_set_features": [vp, vp, i64, i32],
         "gat_set_labels": [vp, vp, i64],
+        "gat_set_train_mask": [vp, vp, i64],
+        "gat_eval_mask": [vp, vp, i64, P(C.c_double), P(i32), P(i32)],
         "gat_set_graph_device": [vp, vp, vp, i64, i64, i64, i64],
         "gat_set_features_device": [vp, vp, i64, i32],
         "gat_set_labels_device": [vp, vp, i64],
@@ -275,6 +277,21 @@ class GatContext:
     def set_labels(self, labels):
         lab = np.ascontiguousarray(labels, np.int32)
         _chk(self.lib.gat_set_labels(self._ctx, _np_ptr(lab), len(lab)))
+
+    def set_train_mask(self, mask):
+        """mask: bool/uint8 [n_rows] (None: every node trains, the reference's behaviour)."""
+        if mask is None:
+            _chk(self.lib.gat_set_train_mask(self._ctx, None, 0))
+            return
+        m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+        _chk(self.lib.gat_set_train_mask(self._ctx, _np_ptr(m), len(m)))
+
+    def eval_mask(self, mask):
+        """-> (loss sum, #correct, #nodes) of the last forward over the nodes of `mask`."""
+        m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+        l, c, n = C.c_double(), C.c_int32(), C.c_int32()
+        _chk(self.lib.gat_eval_mask(self._ctx, _np_ptr(m), len(m), C.byref(l), C.byref(c), C.byref(n)))
+        return l.value, c.value, n.value
 
     def set_labels_device(self, d_labels: int, n_rows: int):
         _chk(self.lib.gat_set_labels_device(self._ctx, C.c_void_p(d_labels), n_rows))

@@ -99,6 +99,9 @@ struct gat_ctx {
     int64_t n_rows = 0, n_edges = 0, n_table = 0, table_row0 = 0;
     bool have_graph = false, have_x = false, have_labels = false, buffers_ready = false;
     int32_t* row_ptr = nullptr; int32_t* col_idx = nullptr; int32_t* labels = nullptr;
+    int32_t* labels_eff = nullptr;                  // with a training mask: label, or ~label outside the mask (gat_set_train_mask)
+    uint8_t* mask_tmp = nullptr;                    // [n_rows] device copy of the mask of the last gat_set_train_mask / gat_eval_mask
+    double* eval_loss = nullptr; int32_t* eval_cnt = nullptr;      // block partials of gat_eval_mask
     float* X0 = nullptr;
     float* Xtab = nullptr;                          // [n_table][in_dim] replicated layer-0 input (gat_set_source_features)
     int64_t nW = 0, nA = 0, nWo = 0;
@@ -319,16 +322,6 @@ static int ensure_buffers(gat_ctx* c) {
     return 0;
 }
 
-static uint64_t splitmix64(uint64_t& s) {
-    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-static float uniform01_open_closed(uint64_t& s) {      // (0, 1] like curand_uniform (E:217)
-    return ((float)(splitmix64(s) >> 40) + 1.0f) * (1.0f / 16777216.0f);
-}
-
 }  // namespace gat
 
 using namespace gat;
@@ -503,6 +496,7 @@ int gat_layer_exchange(gat_ctx* c, int32_t l, int32_t* needed) {
     *needed = (c->n_table != c->n_rows) && !(l == 0 && c->Xtab);
     return 0;
 }
+static void graph_drop_fwd(gat_ctx* c);             // a captured step (gat_step_graph) holds pointers: re-arm when they change
 static int set_labels_common(gat_ctx* c, const int32_t* labels, int64_t n_rows, hipMemcpyKind kind) {
     if (!c || !labels) return fail(GAT_E_INVALID, "gat_set_labels: null argument");
     if (c->have_graph && n_rows != c->n_rows) return fail(GAT_E_INVALID, "Invalid labels length");
@@ -514,6 +508,49 @@ static int set_labels_common(gat_ctx* c, const int32_t* labels, int64_t n_rows, 
     GAT_HIP(hipStreamSynchronize(c->stream));
     c->have_labels = true;
     return ensure_buffers(c);
+}
+// ---- train / validation masks (the reference trains and evaluates on ALL nodes, README R:134: "later") ----------
+static int upload_mask(gat_ctx* c, const uint8_t* mask, int64_t n_rows) {
+    if (!c->have_labels) return fail(GAT_E_STATE, "set the labels first");
+    if (n_rows != c->n_rows && c->have_graph) return fail(GAT_E_INVALID, "mask length differs from the node count");
+    if (!c->mask_tmp) GAT_TRY(dalloc(c, &c->mask_tmp, n_rows));
+    GAT_HIP(hipMemcpyAsync(c->mask_tmp, mask, (size_t)n_rows, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int gat_set_train_mask(gat_ctx* c, const uint8_t* mask, int64_t n_rows) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    if (!mask) {                                    // back to the reference's behaviour: every node trains
+        c->labels_eff = nullptr;                    // (the buffer stays owned by the context)
+        graph_drop_fwd(c);
+        return 0;
+    }
+    GAT_TRY(upload_mask(c, mask, n_rows));
+    int32_t* eff = nullptr;
+    GAT_TRY(dalloc(c, &eff, n_rows));
+    GAT_TRY(launch_apply_mask(c->labels, c->mask_tmp, eff, n_rows, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    c->labels_eff = eff;
+    graph_drop_fwd(c);                              // a captured step holds the old label pointer
+    return 0;
+}
+int gat_eval_mask(gat_ctx* c, const uint8_t* mask, int64_t n_rows, double* loss_sum, int32_t* n_correct, int32_t* n_nodes) {
+    GAT_TRY(check_layer(c, 0));
+    if (!mask) return fail(GAT_E_INVALID, "gat_eval_mask: null mask");
+    if (!c->y_valid) GAT_TRY(gat_head_forward(c, nullptr, nullptr));     // after a fused head step: y = f(H_L, Wo), both still there
+    GAT_TRY(upload_mask(c, mask, n_rows));
+    const int blocks = 256;
+    if (!c->eval_loss) { GAT_TRY(dalloc(c, &c->eval_loss, blocks)); GAT_TRY(dalloc(c, &c->eval_cnt, 2 * blocks)); }
+    GAT_TRY(launch_eval_mask(c->y, c->labels, c->mask_tmp, n_rows, c->cfg.num_classes, c->eval_loss, c->eval_cnt, blocks, c->stream));
+    std::vector<double> hl(blocks); std::vector<int32_t> hc(2 * blocks);
+    GAT_HIP(hipMemcpyAsync(hl.data(), c->eval_loss, blocks * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GAT_HIP(hipMemcpyAsync(hc.data(), c->eval_cnt, 2 * blocks * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    GAT_HIP(hipStreamSynchronize(c->stream));
+    double l = 0.0; int64_t cr = 0, nn = 0;
+    for (int b = 0; b < blocks; ++b) { l += hl[b]; cr += hc[2 * b]; nn += hc[2 * b + 1]; }
+    if (loss_sum) *loss_sum = l;
+    if (n_correct) *n_correct = (int32_t)cr;
+    if (n_nodes) *n_nodes = (int32_t)nn;
+    return 0;
 }
 int gat_set_labels(gat_ctx* c, const int32_t* labels, int64_t n_rows) {
     return set_labels_common(c, labels, n_rows, hipMemcpyHostToDevice);
@@ -587,23 +624,22 @@ int gat_grads_import(gat_ctx* c, const void* d_src, int64_t count) {
 
 int gat_params_init(gat_ctx* c, uint64_t seed) {
     if (!c) return fail(GAT_E_INVALID, "null context");
-    // Same distribution as xavier_init_kernel_curand (E:205-242); own counter-based stream, since
-    // the reference's cuRAND XORWOW stream is seeded with time(NULL) (E:1305) and unreproducible.
-    std::vector<float> h(c->nW + c->nA + c->nWo);
-    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 0x67617432ull;
+    // Same distribution as xavier_init_kernel_curand (E:205-242): U(-lim, lim] with lim = sqrt(6/(2F+D)) for the W rows
+    // and a of a layer, sqrt(6/(C+D_L)) for W_o; own counter-based stream ON THE DEVICE, since the reference's cuRAND
+    // XORWOW stream is seeded with time(NULL) (E:1305) and unreproducible.  Draw order: per layer W then a, then W_o.
+    const uint64_t s0 = seed * 0x9E3779B97F4A7C15ull + 0x67617432ull;
+    uint64_t draw = 0;
     for (int l = 0; l < c->cfg.num_layers; ++l) {
         const Layer& y = c->layers[l];
         const float lim = sqrtf(6.0f / (float)(2 * y.F + y.D));
-        float* w = h.data() + y.w_off;
-        for (int64_t i = 0; i < (int64_t)y.HD * 2 * y.F; ++i) w[i] = uniform01_open_closed(s) * 2.0f * lim - lim;
-        float* a = h.data() + c->nW + y.a_off;
-        for (int i = 0; i < y.HD; ++i) a[i] = uniform01_open_closed(s) * 2.0f * lim - lim;
+        const int64_t nw = (int64_t)y.HD * 2 * y.F;
+        GAT_TRY(launch_xavier_init(c->params + y.w_off, nw, s0, draw, lim, c->stream));
+        draw += (uint64_t)nw;
+        GAT_TRY(launch_xavier_init(c->params + c->nW + y.a_off, y.HD, s0, draw, lim, c->stream));
+        draw += (uint64_t)y.HD;
     }
-    const int DL = c->layers.back().D;
-    const float limo = sqrtf(6.0f / (float)(c->cfg.num_classes + DL));
-    float* wo = h.data() + c->nW + c->nA;
-    for (int64_t i = 0; i < c->nWo; ++i) wo[i] = uniform01_open_closed(s) * 2.0f * limo - limo;
-    GAT_HIP(hipMemcpyAsync(c->params, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const float limo = sqrtf(6.0f / (float)(c->cfg.num_classes + c->layers.back().D));
+    GAT_TRY(launch_xavier_init(c->params + c->nW + c->nA, c->nWo, s0, draw, limo, c->stream));
     GAT_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -639,7 +675,7 @@ int gat_head_forward(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
     GAT_TRY(check_layer(c, 0));
     const Layer& y = c->layers.back();
     HeadArgs a{};
-    a.Wo = Wo_of(c); a.HL = y.hout; a.labels = c->labels; a.y = c->y;
+    a.Wo = Wo_of(c); a.HL = y.hout; a.labels = c->labels_eff ? c->labels_eff : c->labels; a.y = c->y;
     a.loss_partial = c->loss_partial; a.correct_partial = c->correct_partial;
     a.loss_out = c->loss_out; a.correct_out = c->correct_out;
     a.n_rows = c->n_rows; a.C = c->cfg.num_classes; a.DL = y.D;
@@ -663,7 +699,7 @@ int gat_head_backward(gat_ctx* c) {
     GAT_TRY(check_layer(c, 0));
     const Layer& y = c->layers.back();
     HeadBwdArgs a{};
-    a.Wo = Wo_of(c); a.HL = y.hout; a.y = c->y; a.labels = c->labels; a.hpre = y.hpre; a.g = y.g; a.gh_out = c->gH;
+    a.Wo = Wo_of(c); a.HL = y.hout; a.y = c->y; a.labels = c->labels_eff ? c->labels_eff : c->labels; a.hpre = y.hpre; a.g = y.g; a.gh_out = c->gH;
     a.gradWo = gWo_of(c); a.partial = c->hb_partial; a.n_rows = c->n_rows; a.C = c->cfg.num_classes;
     a.DL = y.D; a.H = y.H; a.slope = c->cfg.negative_slope; a.flat_index = c->cfg.flat_lrelu_index;
     Scope t(c, GAT_K_HEAD_BWD);
@@ -757,11 +793,11 @@ static int forward_phases(gat_ctx* c) {
 }
 static void head_args(gat_ctx* c, HeadArgs* f, HeadBwdArgs* b) {
     const Layer& y = c->layers.back();
-    f->Wo = Wo_of(c); f->HL = y.hout; f->labels = c->labels; f->y = c->y;
+    f->Wo = Wo_of(c); f->HL = y.hout; f->labels = c->labels_eff ? c->labels_eff : c->labels; f->y = c->y;
     f->loss_partial = c->loss_partial; f->correct_partial = c->correct_partial;
     f->loss_out = c->loss_out; f->correct_out = c->correct_out;
     f->n_rows = c->n_rows; f->C = c->cfg.num_classes; f->DL = y.D;
-    b->Wo = Wo_of(c); b->HL = y.hout; b->y = c->y; b->labels = c->labels; b->hpre = y.hpre; b->g = y.g; b->gh_out = c->gH;
+    b->Wo = Wo_of(c); b->HL = y.hout; b->y = c->y; b->labels = c->labels_eff ? c->labels_eff : c->labels; b->hpre = y.hpre; b->g = y.g; b->gh_out = c->gH;
     b->gradWo = gWo_of(c); b->partial = c->hb_partial; b->n_rows = c->n_rows; b->C = c->cfg.num_classes;
     b->DL = y.D; b->H = y.H; b->slope = c->cfg.negative_slope; b->flat_index = c->cfg.flat_lrelu_index;
 }
@@ -847,6 +883,8 @@ int gat_backward(gat_ctx* c) {
 // replayed.  First call after arming runs eagerly (fills the occupancy caches, which may not be queried
 // during capture), the second captures, later ones replay.  Everything the step touches has a fixed
 // address once the context is complete; gat_bind_table re-arms.
+static void graph_drop(gat_ctx* c);
+static void graph_drop_fwd(gat_ctx* c) { graph_drop(c); }
 static void graph_drop(gat_ctx* c) {
     if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
     if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }

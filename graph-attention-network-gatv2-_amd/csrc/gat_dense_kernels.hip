@@ -117,8 +117,9 @@ __global__ __launch_bounds__(256) void head_forward_kernel(HeadArgs A, int32_t N
                 if (c == 0 || yv > best) { best = yv; pred = c; }     // strict >, first max wins
                 if (c == lab) plab = yv;
             }
-            loss_acc += (double)(-logf(fmaxf(plab, 1e-12f)));
-            corr_acc += (pred == lab) ? 1 : 0;
+            // lab < 0: the node is outside the training mask (gat_set_train_mask stores ~label): no loss, no count
+            loss_acc += lab >= 0 ? (double)(-logf(fmaxf(plab, 1e-12f))) : 0.0;
+            corr_acc += (lab >= 0 && pred == lab) ? 1 : 0;
         }
         __syncthreads();
         const int rows_here = (int)((A.n_rows - n0 < NB) ? (A.n_rows - n0) : NB);
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(256) void head_backward_kernel(HeadBwdArgs A, int32
             const float* yt = A.y + n0 * C;
             int r = threadIdx.x / C, c = threadIdx.x % C;
             for (int q = threadIdx.x; q < rows_here * C; q += 256) {
-                s_dz[r * ldz + c] = yt[q] - (c == A.labels[n0 + r] ? 1.0f : 0.0f);
+                const int lab_r = A.labels[n0 + r];                    // < 0: outside the training mask => dz = 0
+                s_dz[r * ldz + c] = lab_r >= 0 ? yt[q] - (c == lab_r ? 1.0f : 0.0f) : 0.0f;
                 r += dqC; c += drC;
                 if (c >= C) { c -= C; ++r; }
             }
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(256) void head_backward2_kernel(HeadBwdArgs A, int3
             const float* yt = A.y + n0 * C;
             int r = tid / C, c = tid % C;
             for (int q = tid; q < rows_here * C; q += 256) {
-                s_dz[r * ldz + c] = yt[q] - (c == A.labels[n0 + r] ? 1.0f : 0.0f);
+                const int lab_r = A.labels[n0 + r];                    // < 0: outside the training mask => dz = 0
+                s_dz[r * ldz + c] = lab_r >= 0 ? yt[q] - (c == lab_r ? 1.0f : 0.0f) : 0.0f;
                 r += dqC; c += drC;
                 if (c >= C) { c -= C; ++r; }
             }
@@ -364,10 +367,11 @@ __global__ __launch_bounds__(256) void head_step_kernel(HeadArgs F, HeadBwdArgs 
                 const float yv = (float)((double)zr[c] * rden);
                 if (c == 0 || yv > best) { best = yv; pred = c; }      // strict >, first max wins
                 if (c == lab) plab = yv;
-                zr[c] = yv - (c == lab ? 1.0f : 0.0f);                 // dz
+                zr[c] = lab >= 0 ? yv - (c == lab ? 1.0f : 0.0f) : 0.0f;   // dz (0 outside the training mask)
             }
-            loss_acc += (double)(-logf(fmaxf(plab, 1e-12f)));
-            corr_acc += (pred == lab) ? 1 : 0;
+            // lab < 0: the node is outside the training mask (gat_set_train_mask stores ~label): no loss, no count
+            loss_acc += lab >= 0 ? (double)(-logf(fmaxf(plab, 1e-12f))) : 0.0;
+            corr_acc += (lab >= 0 && pred == lab) ? 1 : 0;
         }
         __syncthreads();
         if (tid < 128) {
@@ -574,6 +578,74 @@ int launch_head_backward(const HeadBwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(head_backward_kernel, dim3(blocks), dim3(256), lds, s, a, NB, ldz, per_thread);
     GAT_HIP(hipGetLastError());
     return launch_reduce_partials_add(a.partial, blocks, (int64_t)a.C * a.DL, a.gradWo, s);
+}
+
+// labels_eff[i] = mask[i] ? labels[i] : ~labels[i]   (mask == nullptr: copy)
+__global__ __launch_bounds__(256) void apply_mask_kernel(const int32_t* __restrict__ labels, const uint8_t* __restrict__ mask,
+                                                         int32_t* __restrict__ eff, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        eff[i] = (mask == nullptr || mask[i]) ? labels[i] : ~labels[i];
+}
+int launch_apply_mask(const int32_t* labels, const uint8_t* mask, int32_t* eff, int64_t n, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, labels, mask, eff, n);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+// Loss / accuracy of the last forward over the nodes of `mask` (validation / test split): per block a fixed-order
+// partial {sum of -log(max(y[label], 1e-12)), #correct, #nodes}; the host adds the block partials in order.
+__global__ __launch_bounds__(256) void eval_mask_kernel(const float* __restrict__ y, const int32_t* __restrict__ labels,
+                                                        const uint8_t* __restrict__ mask, int64_t n, int32_t C,
+                                                        double* __restrict__ part_loss, int32_t* __restrict__ part_cnt) {
+    __shared__ double s_l[256];
+    __shared__ int32_t s_c[256], s_n[256];
+    double l = 0.0; int32_t cr = 0, nn = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (!mask[i]) continue;
+        const float* yr = y + i * C;
+        const int lab = labels[i];
+        float best = -1.f; int pred = 0;
+        for (int c = 0; c < C; ++c) if (c == 0 || yr[c] > best) { best = yr[c]; pred = c; }      // strict >, first max wins (E:530-535)
+        l += (double)(-logf(fmaxf(yr[lab], 1e-12f)));
+        cr += pred == lab; ++nn;
+    }
+    s_l[threadIdx.x] = l; s_c[threadIdx.x] = cr; s_n[threadIdx.x] = nn;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { s_l[threadIdx.x] += s_l[threadIdx.x + off]; s_c[threadIdx.x] += s_c[threadIdx.x + off]; s_n[threadIdx.x] += s_n[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part_loss[blockIdx.x] = s_l[0]; part_cnt[2 * blockIdx.x] = s_c[0]; part_cnt[2 * blockIdx.x + 1] = s_n[0]; }
+}
+int launch_eval_mask(const float* y, const int32_t* labels, const uint8_t* mask, int64_t n, int32_t C, double* part_loss,
+                     int32_t* part_cnt, int32_t blocks, hipStream_t s) {
+    hipLaunchKernelGGL(eval_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, labels, mask, n, C, part_loss, part_cnt);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+// Xavier-uniform init on the device (E:186-248): element i of a segment = the (draw0 + i)-th draw of the
+// counter-based stream  z_k = splitmix64_finalise(s0 + (k+1)*0x9E3779B97F4A7C15)  mapped to (0, 1] like
+// curand_uniform (E:217) and then to (-lim, lim].
+__global__ __launch_bounds__(256) void xavier_init_kernel(float* __restrict__ p, int64_t n, uint64_t s0, uint64_t draw0, float lim) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t z = s0 + (draw0 + (uint64_t)i + 1ull) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const float u = ((float)(z >> 40) + 1.0f) * (1.0f / 16777216.0f);
+        p[i] = u * 2.0f * lim - lim;
+    }
+}
+int launch_xavier_init(float* p, int64_t n, uint64_t s0, uint64_t draw0, float lim, hipStream_t s) {
+    if (n <= 0) return 0;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(xavier_init_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, s0, draw0, lim);
+    GAT_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_sgd(float* p, const float* g, float lr, int64_t n, hipStream_t s) {

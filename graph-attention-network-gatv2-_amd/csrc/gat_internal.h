@@ -231,6 +231,13 @@ int launch_head_backward(const HeadBwdArgs& a, hipStream_t s);
 bool head_step_supported(const HeadBwdArgs& b);
 int launch_head_step(const HeadArgs& f, const HeadBwdArgs& b, hipStream_t s);
 
+// train / validation masks (README R:134 "later"): labels_eff = mask ? label : ~label — the head kernels skip negative
+// labels (no loss, no count, dz = 0); eval_mask: fixed-order block partials of loss / #correct / #nodes over a mask
+int launch_apply_mask(const int32_t* labels, const uint8_t* mask, int32_t* eff, int64_t n, hipStream_t s);
+int launch_eval_mask(const float* y, const int32_t* labels, const uint8_t* mask, int64_t n, int32_t C, double* part_loss,
+                     int32_t* part_cnt, int32_t blocks, hipStream_t s);
+// p[i] = the (draw0+i)-th draw of the seeded counter stream mapped to (-lim, lim]  (Xavier-uniform, E:186-248)
+int launch_xavier_init(float* p, int64_t n, uint64_t s0, uint64_t draw0, float lim, hipStream_t s);
 int launch_sgd(float* p, const float* g, float lr, int64_t n, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, float lr, int64_t n, float b1, float b2,
                 float eps, int32_t t, hipStream_t s);

@@ -59,6 +59,7 @@ struct Options {
     int ranks = 1;
     std::string transport = "rccl";
     std::string dtype = "f32";
+    std::string train_mask, val_mask;     // text files of N 0/1 values (beyond the reference: README R:134 "later")
 };
 
 struct RankEnv {                      // one forked process per GPU
@@ -115,6 +116,8 @@ Options parse_args(int argc, char** argv) {
         else if (a == "--dataset" && has_val) o.dataset = argv[++i];
         else if (a == "--data-root" && has_val) o.data_root = argv[++i];
         else if (a == "--seed" && has_val) { o.seed = std::strtoull(argv[++i], nullptr, 0); o.seed_given = true; }
+        else if (a == "--train-mask" && has_val) o.train_mask = argv[++i];
+        else if (a == "--val-mask" && has_val) o.val_mask = argv[++i];
         else if (a == "--load-params" && has_val) o.load_params = argv[++i];
         else if (a == "--dump-params" && has_val) o.dump_params = argv[++i];
         else if (a == "--device" && has_val) o.device = std::stoi(argv[++i]);
@@ -378,6 +381,30 @@ int run(const Options& o, const RankEnv& env) {
             check(gat_comm_init_host(ctx, env.world, env.rank, env.shm_name.c_str(), bytes), "gat_comm_init_host");
         }
     }
+    // optional splits: loss / accuracy / gradient over the training nodes, an extra validation line per epoch
+    std::vector<uint8_t> train_m, val_m;
+    int64_t n_train = N;
+    auto load_mask = [&](const std::string& file, std::vector<uint8_t>& m, const char* what) {
+        std::vector<int32_t> v;
+        load_ints(file, v);
+        if ((int64_t)v.size() != N) die(std::string("Invalid ") + what + " length\n");
+        m.resize((size_t)N);
+        for (int64_t i = 0; i < N; ++i) m[(size_t)i] = v[(size_t)i] != 0;
+    };
+    if (!o.train_mask.empty()) {
+        load_mask(o.train_mask, train_m, "train mask");
+        n_train = 0;
+        for (uint8_t b : train_m) n_train += b;
+        if (n_train == 0) die("Error: --train-mask selects no node\n");
+        const int64_t r0 = env.world == 1 ? 0 : gatshard::make_plan(row_ptr.data(), N, env.world, env.rank).row0();
+        const int64_t nr = env.world == 1 ? N : gatshard::make_plan(row_ptr.data(), N, env.world, env.rank).n_rows();
+        check(gat_set_train_mask(ctx, train_m.data() + r0, nr), "gat_set_train_mask");
+        std::printf("Training nodes: %lld of %lld\n", (long long)n_train, (long long)N);
+    }
+    if (!o.val_mask.empty()) {
+        if (env.world != 1) die("Error: --val-mask needs --ranks 1\n");
+        load_mask(o.val_mask, val_m, "val mask");
+    }
     check(gat_params_init(ctx, o.seed), "xavier_init_kernel");
     if (!o.load_params.empty()) {
         std::vector<float> p(nW + nA + nWo);
@@ -401,7 +428,12 @@ int run(const Options& o, const RankEnv& env) {
         std::printf("\nEpoch %d\n", epoch);
         float loss_sum = 0.f; int32_t n_correct = 0;
         check(gat_forward(ctx, &loss_sum, &n_correct), "gatv2 forward");
-        std::printf("\nAvg Loss: %f, Accuracy: %.2f%%\n", loss_sum / N, 100.0f * (static_cast<float>(n_correct) / N));
+        std::printf("\nAvg Loss: %f, Accuracy: %.2f%%\n", loss_sum / n_train, 100.0f * (static_cast<float>(n_correct) / n_train));
+        if (!val_m.empty()) {
+            double vl = 0.0; int32_t vc = 0, vn = 0;
+            check(gat_eval_mask(ctx, val_m.data(), N, &vl, &vc, &vn), "gat_eval_mask");
+            std::printf("Val Loss: %f, Val Accuracy: %.2f%%\n", vn ? vl / vn : 0.0, vn ? 100.0f * (static_cast<float>(vc) / vn) : 0.0f);
+        }
         check(gat_backward(ctx), "gatv2 backward");
         if (o.clip) check(gat_clip(ctx, 5.0f), "clip_grad_norm");                   // E:1563
         if (o.optimizer == "adam") check(gat_step_adam(ctx, o.lr, o.beta1, o.beta2, 1e-8f, epoch), "adam_update_kernel");

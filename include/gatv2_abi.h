@@ -84,6 +84,13 @@ int gat_set_graph(gat_ctx* ctx, const int32_t* row_ptr, const int32_t* col_idx, 
                   int64_t n_edges, int64_t n_table, int64_t table_row0);
 int gat_set_features(gat_ctx* ctx, const float* x, int64_t n_rows, int32_t in_dim);   /* [n_rows][F0] */
 int gat_set_labels(gat_ctx* ctx, const int32_t* labels, int64_t n_rows);
+/* Train / validation / test splits — beyond the reference, which trains and evaluates on ALL nodes (E:514-537,
+ * README R:134 "later").  mask[n_rows]: 1 = the node belongs to the split.  With a training mask, loss, #correct and
+ * the output gradient dz = y - onehot (E:571-573) are taken over the masked nodes only (every node still takes part in
+ * the message passing); NULL restores the reference's behaviour.  gat_eval_mask: loss sum / #correct / #nodes of the
+ * LAST forward over another split (call after gat_forward or gat_step). */
+int gat_set_train_mask(gat_ctx* ctx, const uint8_t* mask, int64_t n_rows);
+int gat_eval_mask(gat_ctx* ctx, const uint8_t* mask, int64_t n_rows, double* loss_sum, int32_t* n_correct, int32_t* n_nodes);
 /* Device-resident variants (pointers on ctx's device; copied D2D). */
 int gat_set_graph_device(gat_ctx* ctx, const int32_t* d_row_ptr, const int32_t* d_col_idx,
                          int64_t n_rows, int64_t n_edges, int64_t n_table, int64_t table_row0);

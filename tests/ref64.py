@@ -70,15 +70,18 @@ def forward(cfg, row_ptr, col_idx, labels, X, W, a, Wo):
     return dict(layers=layers, HL=x, Wo=Wom, y=y, src=src, dst=dst, row_ptr=row_ptr, labels=np.asarray(labels), N=N)
 
 
-def backward(cfg, fw, mask_s_params, mask_s_gx, mask_h):
+def backward(cfg, fw, mask_s_params, mask_s_gx, mask_h, node_mask=None):
     """mask_s_params[l], mask_s_gx[l]: bool [E,H,D], True = LeakyReLU' took the positive branch at s — as used for
     the parameter gradients (E:774) and for the input-feature gradients (E:855); mask_h[l]: bool [N,H,D] for
-    LeakyReLU'(h_pre) (E:599 last layer, E:890 hidden layers).  -> dict of every gradient tensor (fp64)."""
+    LeakyReLU'(h_pre) (E:599 last layer, E:890 hidden layers); node_mask: optional [N] 0/1 training split.
+    -> dict of every gradient tensor (fp64)."""
     N, src, dst, rp = fw["N"], fw["src"], fw["dst"], fw["row_ptr"]
     L = cfg.L
     y = fw["y"]
     dz = y.copy()
     dz[np.arange(N), fw["labels"]] -= 1.0                                # E:571-573 (sum loss, no 1/N)
+    if node_mask is not None:                                            # training split (gat_set_train_mask): dz = 0 outside
+        dz *= np.asarray(node_mask, np.float64)[:, None]
     gradWo = dz.T @ fw["HL"]
     gH = dz @ fw["Wo"]                                                   # [N,DL]
     HL_ = cfg.heads[-1]

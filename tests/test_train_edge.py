@@ -174,3 +174,36 @@ def test_binary_cache_gives_the_same_run(pkg, tmp_path):
     third = run(args)                          # a text file newer than the cache: re-parsed and rewritten
     assert third.returncode == 0 and re.findall(pat, first.stdout) == re.findall(pat, third.stdout)
     assert cache.stat().st_mtime_ns > before
+
+
+@pytest.mark.gpu
+def test_train_and_val_masks_through_the_binary(pkg, orc, tmp_path):
+    """--train-mask / --val-mask (beyond the reference, README R:134 "later"): the first epoch's printed numbers
+    equal the fp64 forward restricted to the splits; without the flags the output is the reference's."""
+    import ref64
+    ds = pkg.synth.make_dataset("cora", scale=0.2)
+    pkg.synth.write_text_dataset(ds, str(tmp_path), "tiny")
+    x = np.loadtxt(tmp_path / "tiny" / "features.txt", dtype=np.float32, ndmin=2)
+    n = ds["n"]
+    rng = np.random.default_rng(4)
+    train = rng.random(n) < 0.5
+    val = ~train
+    np.savetxt(tmp_path / "train.txt", train.astype(int), fmt="%d")
+    np.savetxt(tmp_path / "val.txt", val.astype(int), fmt="%d")
+    cfg = orc.Config([8, 8], [8, 8], ds["f"], ds["c"])
+    W, a, Wo = orc.xavier_params(cfg, 7)
+    pfile = tmp_path / "p.bin"
+    np.concatenate([W, a, Wo]).astype(np.float32).tofile(pfile)
+    r = run(["--dataset", "tiny", "--data-root", str(tmp_path), "--heads", "8,8", "--outdims", "8,8", "--epochs", "1",
+             "--load-params", str(pfile), "--train-mask", str(tmp_path / "train.txt"), "--val-mask", str(tmp_path / "val.txt")])
+    assert r.returncode == 0, r.stderr
+    fw = ref64.forward(cfg, ds["row_ptr"], ds["col_idx"], ds["labels"], x, W, a, Wo)
+    nll = -np.log(np.maximum(fw["y"][np.arange(n), ds["labels"]], 1e-12)); ok = fw["y"].argmax(1) == ds["labels"]
+    m = re.search(r"Avg Loss: ([0-9.]+), Accuracy: ([0-9.]+)%\nVal Loss: ([0-9.]+), Val Accuracy: ([0-9.]+)%", r.stdout)
+    assert m, r.stdout
+    assert f"Training nodes: {int(train.sum())} of {n}\n" in r.stdout
+    assert abs(float(m.group(1)) - nll[train].mean()) < 1e-4 and abs(float(m.group(2)) - 100.0 * ok[train].mean()) < 0.011
+    assert abs(float(m.group(3)) - nll[val].mean()) < 1e-4 and abs(float(m.group(4)) - 100.0 * ok[val].mean()) < 0.011
+    bad = run(["--dataset", "tiny", "--data-root", str(tmp_path), "--heads", "8,8", "--outdims", "8,8", "--epochs", "1",
+               "--train-mask", str(tmp_path / "tiny" / "row_ptr.txt")])
+    assert bad.returncode == 1 and "Invalid train mask length" in bad.stderr
