@@ -9,14 +9,14 @@
 //   RcclComm : RCCL over xGMI, enqueued on the context's stream.  librccl is dlopen'ed at
 //              gat_comm_init_rccl — single-GPU users of libgatv2_hip.so never load it, and inside a
 //              torch process the copy torch already loaded (same soname) is the one that binds.
-//   HostComm : staged through a POSIX shared-memory segment with a process-shared barrier; sums in
-//              ascending rank order (bitwise identical on every rank).  For tests (several ranks
-//              sharing one GPU, which RCCL refuses) and boxes without peer links.
+//   HostComm : staged through a POSIX shared-memory segment, ranks meeting at a generation barrier with a
+//              deadline (a dead peer makes the others return GAT_E_COMM, not hang); sums in ascending rank
+//              order (bitwise identical on every rank).  For tests (several ranks sharing one GPU, which
+//              RCCL refuses) and boxes without peer links.
 #include "gat_internal.h"
 
 #include <dlfcn.h>
 #include <fcntl.h>
-#include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -105,12 +105,22 @@ struct RcclComm final : Comm {
 };
 
 // ---- host-staged transport ------------------------------------------------------------------------------
+// The meeting point is a generation barrier on two words of the segment, polled with a deadline — not a
+// pthread_barrier, which has no timeout: a rank whose peer died (or never reached the exchange) would wait for ever.
+// On a timeout the rank also raises `failed`, which every other waiter checks, so that the whole group returns
+// GAT_E_COMM within one polling interval instead of each rank running into its own deadline.
 struct ShmHeader {
-    pthread_barrier_t barrier;
+    uint32_t arrived;              // ranks that reached the current meeting
+    uint32_t generation;           // bumped by the last arriver
+    int32_t failed;                // set by the first rank that gave up; sticky
     int32_t world;
-    int32_t ready;                 // set by rank 0 once the barrier is initialised
+    int32_t ready;                 // set by rank 0 once the header is initialised
     int64_t bytes_per_rank;
 };
+static double comm_timeout_s() {   // GAT_COMM_TIMEOUT_S (default 120 s): how long a rank waits for its peers at an exchange
+    static const double v = [] { const char* e = getenv("GAT_COMM_TIMEOUT_S"); const double x = e ? atof(e) : 0.0; return x > 0.0 ? x : 120.0; }();
+    return v;
+}
 constexpr size_t kShmHeader = 4096;
 
 struct HostComm final : Comm {
@@ -126,9 +136,31 @@ struct HostComm final : Comm {
         if (rank == 0 && !name.empty()) shm_unlink(name.c_str());
     }
     int meet() {
-        const int r = pthread_barrier_wait(&hdr()->barrier);
-        if (r != 0 && r != PTHREAD_BARRIER_SERIAL_THREAD) return fail(GAT_E_COMM, "host transport: barrier failed");
-        return 0;
+        ShmHeader* h = hdr();
+        if (__atomic_load_n(&h->failed, __ATOMIC_ACQUIRE)) return fail(GAT_E_COMM, "host transport: a peer gave up at an earlier exchange");
+        const uint32_t gen = __atomic_load_n(&h->generation, __ATOMIC_ACQUIRE);
+        if (__atomic_add_fetch(&h->arrived, 1u, __ATOMIC_ACQ_REL) == (uint32_t)world) {
+            __atomic_store_n(&h->arrived, 0u, __ATOMIC_RELAXED);
+            __atomic_store_n(&h->generation, gen + 1u, __ATOMIC_RELEASE);
+            return 0;
+        }
+        struct timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int spin = 0;; ++spin) {
+            if (__atomic_load_n(&h->generation, __ATOMIC_ACQUIRE) != gen) return 0;
+            if (__atomic_load_n(&h->failed, __ATOMIC_ACQUIRE)) return fail(GAT_E_COMM, "host transport: a peer gave up waiting (see its error)");
+            if (spin > 2000) { struct timespec ts = {0, 200 * 1000}; nanosleep(&ts, nullptr); }       // 0.2 ms once the peers are clearly late
+            if ((spin & 255) == 255) {
+                struct timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                const double waited = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+                if (waited > comm_timeout_s()) {
+                    __atomic_store_n(&h->failed, 1, __ATOMIC_RELEASE);
+                    return fail(GAT_E_COMM, "host transport: rank " + std::to_string(rank) + " waited " + std::to_string((int)waited) +
+                                                " s at an exchange for peers that did not arrive (dead or stuck rank; GAT_COMM_TIMEOUT_S)");
+                }
+            }
+        }
     }
     int fits(int64_t floats) const {
         if (floats * (int64_t)sizeof(float) > bytes_per_rank)
@@ -231,11 +263,7 @@ int comm_create_host(int world, int rank, const char* shm_name, int64_t bytes_pe
     c->base = (char*)p;
     ShmHeader* h = c->hdr();
     if (rank == 0) {
-        pthread_barrierattr_t at;
-        pthread_barrierattr_init(&at);
-        pthread_barrierattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
-        if (pthread_barrier_init(&h->barrier, &at, (unsigned)world) != 0) return fail(GAT_E_COMM, "pthread_barrier_init failed");
-        pthread_barrierattr_destroy(&at);
+        h->arrived = 0; h->generation = 0; h->failed = 0;       // (a fresh segment is zero-filled anyway)
         h->world = world; h->bytes_per_rank = c->bytes_per_rank;
         __atomic_store_n(&h->ready, 1, __ATOMIC_RELEASE);
     } else {
