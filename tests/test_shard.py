@@ -413,7 +413,10 @@ def test_dead_peer_makes_the_other_ranks_fail_not_hang(pkg):
     world = 3
     with tempfile.TemporaryDirectory() as d:
         ctxs = mp.spawn(_dead_peer_worker, args=(world, d, f"/gatv2_dead_{os.getpid()}"), nprocs=world, join=False)
-        ok = ctxs.join(timeout=120)
+        import time
+        t_end = time.time() + 120
+        while time.time() < t_end and not ctxs.join(timeout=5):     # join() returns at the FIRST exit: loop until all are gone
+            pass
         for p in ctxs.processes:
             if p.is_alive():
                 p.terminate()
