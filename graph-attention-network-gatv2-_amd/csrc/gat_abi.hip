@@ -41,7 +41,10 @@ struct Pending { int k; hipEvent_t e0, e1; };
 
 void build_worklist(const int32_t* rp, int64_t n_rows, WorkList& w) {
     static const int seg_env = [] { const char* e = getenv("GAT_SEG_EDGES"); const int v = e ? atoi(e) : 0; return v >= 16 ? v : 0; }();
-    const int kSegEdges = seg_env ? seg_env : gat::kSegEdges;       // GAT_SEG_EDGES=<n>: sweep of the hub-row segment length
+    // GAT_SEG_EDGES=<n>: sweep of the hub-row segment length.  Default 256 (swept on the Products shape); graphs with
+    // few edges get shorter segments: the persistent backward's critical path is its longest item (a 256-edge segment
+    // is 64 dependent gather steps), which at Arxiv size (1.17 M edges) was longer than everything else together
+    const int kSegEdges = seg_env ? seg_env : (rp[n_rows] < (16 << 20) ? 64 : gat::kSegEdges);
     w.items.clear(); w.slot_info.clear(); w.n_slots = 0; w.n_split = 0;
     std::vector<int32_t> firsts;
     // pass 1: segments of split rows first (the longest items start earliest)
@@ -269,7 +272,10 @@ static int ensure_buffers(gat_ctx* c) {
         Layer& y = c->layers[l];
         if (!edge_fast_path(y.H, y.D, c->n_table)) continue;
         const int w = edge_stash_words(y.H, y.D);
-        y.stash = w > 0 && !bf16(c) && !c->cfg.keep_taps && !(no_stash && no_stash[0] == '0');
+        // bf16 storage: only where the message row (H*D*2 bytes) is larger than a record — at H*D = 32 the record path
+        // trades a 64-B streamed row for a 32-B record plus a 64-B random gather and loses (10 M / 250 M shape: the
+        // source-major pass 8.4 -> 13.4 ms per step, the destination-major pass unchanged)
+        y.stash = w > 0 && !c->cfg.keep_taps && !(no_stash && no_stash[0] == '0') && !(bf16(c) && y.HD < 64);
         if (y.stash) stash_words = std::max(stash_words, w); else msg_hd = std::max(msg_hd, y.HD);
     }
     const char* force = getenv("GAT_BWD_ATOMICS");
@@ -736,7 +742,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     }
     if (stash) {
         Scope t(c, GAT_K_GPL_SUM);
-        GAT_TRY(launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, a_of(c, l), c->cfg.negative_slope, c->gPL, c->n_table,
+        GAT_TRY(launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, bf16(c), a_of(c, l), c->cfg.negative_slope, c->gPL, c->n_table,
                                 c->n_edges, y.H, y.D, c->gpl_chunks, c->n_gpl_chunks, c->gpl_heavy, c->n_gpl_heavy, c->gpl_part,
                                 c->stream));
     } else if (store) {

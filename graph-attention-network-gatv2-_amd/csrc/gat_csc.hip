@@ -281,7 +281,7 @@ template <int N> struct PullVec;
 template <> struct PullVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <> struct PullVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
 
-template <int HD, int N>
+template <int HD, int N, bool BF>
 __device__ __forceinline__ typename PullVec<N>::T pull_range(const uint32_t* __restrict__ stash,
                                                              const int32_t* __restrict__ cdst,
                                                              const float* __restrict__ gfull, int b, int e, int lane,
@@ -308,8 +308,21 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range(const uint32_t* __r
             const int i = i0 + u * G + gidx;
             const int ic = i < e ? i : e - 1;                   // clamped: loads need no predicate
             w[u] = stash[(uint64_t)(uint32_t)ic * LPE + cp];
-            const uint32_t off = (uint32_t)__shfl(dv, u * G + gidx) * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4);
-            g[u] = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + off);
+            const uint32_t drow = (uint32_t)__shfl(dv, u * G + gidx);
+            if constexpr (BF) {                                   // g rows stored as bf16 (cfg.storage_dtype): 2*N bytes per lane
+                const char* p = reinterpret_cast<const char*>(gfull) + drow * (uint32_t)(HD * 2) + (uint32_t)cp * (uint32_t)(N * 2);
+                if constexpr (N == 2) {
+                    const uint32_t w2 = *reinterpret_cast<const uint32_t*>(p);
+                    g[u][0] = __builtin_bit_cast(float, w2 << 16); g[u][1] = __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+                } else {
+                    const uint2 w2 = *reinterpret_cast<const uint2*>(p);
+                    g[u][0] = __builtin_bit_cast(float, w2.x << 16); g[u][1] = __builtin_bit_cast(float, w2.x & 0xFFFF0000u);
+                    g[u][2] = __builtin_bit_cast(float, w2.y << 16); g[u][3] = __builtin_bit_cast(float, w2.y & 0xFFFF0000u);
+                }
+            } else {
+                const uint32_t off = drow * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4);
+                g[u] = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + off);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -332,7 +345,7 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range(const uint32_t* __r
     return acc;
 }
 
-template <int HD, int N>
+template <int HD, int N, bool BF>
 __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict__ src_ptr, const uint32_t* __restrict__ stash,
                                                        const int32_t* __restrict__ cdst, const float* __restrict__ gfull,
                                                        const float* __restrict__ a, float slope, float* __restrict__ gPL,
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
     V acc;
     if (b < e) {
         const V ac = *reinterpret_cast<const V*>(a + cp * N);
-        acc = pull_range<HD, N>(stash, cdst, gfull, b, e, lane, ac, ac * slope);
+        acc = pull_range<HD, N, BF>(stash, cdst, gfull, b, e, lane, ac, ac * slope);
     } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = 0.f;
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
     if (lane < LPE) *reinterpret_cast<V*>(gPL + s * HD + cp * N) = acc;
 }
 
-template <int HD, int N>
+template <int HD, int N, bool BF>
 __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restrict__ chunks, int32_t n_chunks,
                                                              const uint32_t* __restrict__ stash, const int32_t* __restrict__ cdst,
                                                              const float* __restrict__ gfull, const float* __restrict__ a,
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restr
     const int4 ch = chunks[k];                          // {first slot, end slot, partial row, -}, never empty
     const int cp = lane % LPE;
     const V ac = *reinterpret_cast<const V*>(a + cp * N);
-    const V acc = pull_range<HD, N>(stash, cdst, gfull, ch.x, ch.y, lane, ac, ac * slope);
+    const V acc = pull_range<HD, N, BF>(stash, cdst, gfull, ch.x, ch.y, lane, ac, ac * slope);
     if (lane < LPE) *reinterpret_cast<V*>(part + (int64_t)ch.z * HD + cp * N) = acc;
 }
 
@@ -399,30 +412,31 @@ int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int
     return 0;
 }
 
-template <int HD, int N>
+template <int HD, int N, bool BF>
 static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const float* a,
                     float slope, float* gPL, int64_t n_table, const int4* chunks, int32_t n_chunks, const int4* heavy,
                     int32_t n_heavy, float* part, int wpb, hipStream_t s) {
     if (n_heavy > 0) {                                  // long lists first: they are the longest-running waves
-        hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
+        hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, BF>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
                            stash, cdst, gfull, a, slope, part);
         const int64_t threads = (int64_t)n_heavy * HD;
         hipLaunchKernelGGL(gpl_heavy_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, heavy, n_heavy, part, gPL, HD);
     }
-    hipLaunchKernelGGL((gpl_pull_kernel<HD, N>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
+    hipLaunchKernelGGL((gpl_pull_kernel<HD, N, BF>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
                        cdst, gfull, a, slope, gPL, n_table, heavy_slots());
     GAT_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const float* a,
+int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16, const float* a,
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
                     int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, hipStream_t s) {
     (void)n_slots;
     if (n_table <= 0) return 0;
     static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
     const int HD = H * D;
-#define PULL(HD_, N_) return run_pull<HD_, N_>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, s)
+#define PULL(HD_, N_) return g_bf16 ? run_pull<HD_, N_, true>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, s) \
+                                     : run_pull<HD_, N_, false>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, s)
     if (D == 8 && HD == 64) PULL(64, 4);
     if (D == 8 && HD == 32) PULL(32, 4);
     if (D == 4 && HD == 64) PULL(64, 2);

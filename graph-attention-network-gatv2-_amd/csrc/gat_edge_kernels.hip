@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
 // Group-per-row backward with per-edge records (see edge_fwd3_kernel and the STASH note at bwd2_chunk): persistent
 // waves take quads of G work items (static round-robin over the length-sorted list: every wave gets the same mix).
-template <int HD, int D, int N, int DBG = 0>
+template <int HD, int D, int N, int DBG = 0, bool BF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void edge_bwd3_kernel(EdgeBwdArgs A) {
     constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
     constexpr int U = 4;
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const float m2 = A.mstat[rowc * H + c / D];
         const float inv = __builtin_amdgcn_rcpf(A.zstat[rowc * H + c / D] + 1e-8f);
         if (row >= 0 && (slot < 0 || b == A.row_ptr[rowc]))      // one writer per row: whole rows, or a split row's first segment
-            *reinterpret_cast<vnf<N>*>(A.gfull + rowc * HD + c) = g;
+            store_row_n<HD, N, BF>(A.gfull, (int)rowc, cp, g);       // bf16 storage: the gathered g table is 2-byte too
         vnf<N> gpr = vzero<N>();
         const int nst = wave_max_over_groups<HD, N>((e - b + U - 1) / U);
         // Software pipeline.  vmcnt retires loads AND stores in issue order, so a store issued ahead of a gather makes the
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         for (int st = 0; st < nst; ++st) {
             vnf<N> v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) v[u] = gather_row_n<HD, N, false>(A.PL, src[u], cp);
+            for (int u = 0; u < U; ++u) v[u] = gather_row_n<HD, N, BF>(A.PL, src[u], cp);
             if constexpr (DBG == 3) {                // timing experiment: the step's bytes as ONE 16-B-per-lane store, CSR order
                 const int j0 = b + (st > 0 ? st - 1 : 0) * U;
                 uint4 w4 = make_uint4(pend_w[0], pend_w[1], pend_w[2], pend_w[3]);
@@ -1296,9 +1296,11 @@ static bool packed_backward() { return packed_layout(); }
 struct BwdSel { bool store, taps, bf16, stash; };
 template <int HD, int D, bool BF>
 const void* bwd_variant(bool store, bool taps, bool stash = false) {
-    if constexpr (stash_n<HD, D>() != 0 && !BF) {
-        if (stash && !taps) return row_groups() ? (const void*)edge_bwd3_kernel<HD, D, stash_n<HD, D>()>
-                                                : (const void*)edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>;
+    if constexpr (stash_n<HD, D>() != 0) {
+        if (stash && !taps) {
+            if (BF) return (const void*)edge_bwd3_kernel<HD, D, stash_n<HD, D>(), 0, true>;
+            return row_groups() ? (const void*)edge_bwd3_kernel<HD, D, stash_n<HD, D>()> : (const void*)edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>;
+        }
     }
     if constexpr (D % 2 == 0) {
         if (store && !taps && packed_backward()) {
@@ -1313,7 +1315,7 @@ const void* bwd_variant(bool store, bool taps, bool stash = false) {
 }
 template <int HD, int D>
 int bwd_resident(const BwdSel& sel, hipStream_t) {
-    return resident_blocks(sel.bf16 ? bwd_variant<HD, D, true>(sel.store, sel.taps) : bwd_variant<HD, D, false>(sel.store, sel.taps, sel.stash));
+    return resident_blocks(sel.bf16 ? bwd_variant<HD, D, true>(sel.store, sel.taps, sel.stash) : bwd_variant<HD, D, false>(sel.store, sel.taps, sel.stash));
 }
 
 template <int HD, int D>
@@ -1327,6 +1329,11 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
     }
     bool launched = false;
     if constexpr (stash_n<HD, D>() != 0) {
+        if (a.stash != nullptr && !taps && a.bf16) {                // bf16 storage: always the group-per-row kernel
+            if (a.gfull == nullptr || a.pos == nullptr) return fail(GAT_E_INVALID, "edge_backward: stash path needs gfull and pos");
+            hipLaunchKernelGGL((edge_bwd3_kernel<HD, D, stash_n<HD, D>(), 0, true>), grid, block, 0, s, a);
+            launched = true;
+        }
         if (a.stash != nullptr && !taps && !a.bf16) {
             if (a.gfull == nullptr || a.pos == nullptr) return fail(GAT_E_INVALID, "edge_backward: stash path needs gfull and pos");
             bool dbg_done = false;

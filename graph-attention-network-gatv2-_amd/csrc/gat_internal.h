@@ -136,7 +136,7 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
 // cdst[pos[e]] = destination row of CSR edge e (the source-major twin of a1's dst array; built once per graph)
 int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int64_t n_rows, int64_t n_edges, hipStream_t s);
 // Stash path: gPL[s][:] = sum over the slots of s of  g[cdst][:] * alpha + ge * a (.) LReLU'  rebuilt from the records
-int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const float* a,
+int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16, const float* a,
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
                     int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, hipStream_t s);
 
