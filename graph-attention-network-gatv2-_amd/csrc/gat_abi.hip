@@ -295,7 +295,7 @@ static int ensure_buffers(gat_ctx* c) {
             GAT_TRY(build_csc(c->col_idx, E, T, c->csc_pos, c->csc_ptr, c->stream));
             if (c->csc_dst) GAT_TRY(build_csc_dst(c->row_ptr, c->csc_pos, c->csc_dst, N, E, c->stream));
             HeavyList hl;
-            GAT_TRY(build_heavy_list(c->csc_ptr, T, &hl, c->stream));
+            GAT_TRY(build_heavy_list(c->csc_ptr, T, E, &hl, c->stream));
             c->n_gpl_chunks = (int32_t)(hl.chunks.size() / 4); c->n_gpl_heavy = (int32_t)(hl.heavy.size() / 4);
             if (c->n_gpl_heavy > 0) {
                 GAT_TRY(dalloc(c, &c->gpl_chunks, c->n_gpl_chunks));
@@ -316,6 +316,7 @@ static int ensure_buffers(gat_ctx* c) {
     int64_t gw = 1;
     for (int l = 0; l < L; ++l) gw = std::max(gw, grad_w_scratch_floats(N, c->layers[l].F, c->layers[l].HD));
     if (c->Xtab) gw = std::max(gw, grad_w_scratch_floats(T, c->layers[0].F, c->layers[0].HD));
+    for (int l = 0; l < L; ++l) gw = std::max(gw, project_scratch_floats(l == 0 && c->Xtab ? T : N, c->layers[l].F, c->layers[l].HD));   // split-K projection (few rows, long K)
     GAT_TRY(dalloc(c, &c->gw_scratch, gw));
     const int C = c->cfg.num_classes, DL = c->layers[L - 1].D;
     GAT_TRY(dalloc(c, &c->hb_partial, (int64_t)head_bwd_blocks(N, C, DL) * C * DL));
@@ -656,11 +657,11 @@ int gat_layer_project(gat_ctx* c, int32_t l) {
     Layer& y = c->layers[l];
     Scope t(c, GAT_K_PROJECT);
     if (l == 0 && c->Xtab) {      // replicated input: whole PL table from the table rows, PR from the shard's rows
-        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->stream));
-        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->stream);
+        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->gw_scratch, c->stream));
+        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->gw_scratch, c->stream);
     }
     float* own_rows = reinterpret_cast<float*>(reinterpret_cast<char*>(y.PL) + c->table_row0 * y.HD * st_bytes(c));
-    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->stream);
+    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->stream);
 }
 
 int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
@@ -1192,7 +1193,7 @@ int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, con
     float *PL, *PR, *alpha, *ms, *zs;
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
     GAT_TRY(t.get(&ms, n * h)); GAT_TRY(t.get(&zs, n * h));
-    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, s));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, nullptr, s));
     EdgeFwdArgs a{};
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
     a.mstat = ms; a.zstat = zs;
@@ -1220,7 +1221,7 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
     GAT_TRY(t.get(&gPL, n * HD)); GAT_TRY(t.get(&gPR, n * HD)); GAT_TRY(t.get(&gap, (int64_t)blocks * HD));
     GAT_TRY(t.get(&scr, grad_w_scratch_floats(n, f, HD)));
-    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, s));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, nullptr, s));
     GAT_TRY(launch_transpose_he_to_eh(d_attn_coeff, alpha, e, h, s));
     GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
     // softmax stats of this layer (the fast-path backward recomputes alpha from them): one

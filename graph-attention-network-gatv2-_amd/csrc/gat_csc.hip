@@ -42,9 +42,11 @@ __global__ __launch_bounds__(256) void segment_offsets_kernel(const int32_t* __r
 // flight and become the tail of the launch — 13 k slots = 1.7 ms alone) are cut into chunks of kHeavySlots,
 // one wave each, partial rows summed per source in chunk order by a small second kernel (deterministic).
 constexpr int kHeavySlotsDefault = 512;    // swept on the Products shape: 64..1024, 512 best (5.83 -> 5.56 ms per step vs 256)
-static int heavy_slots() {                              // GAT_GPL_HEAVY=<n> overrides (tests: huge = never chunk)
-    static const int v = [] { const char* e = getenv("GAT_GPL_HEAVY"); const int x = e ? atoi(e) : 0; return x > 0 ? x : kHeavySlotsDefault; }();
-    return v;
+// GAT_GPL_HEAVY=<n> overrides (tests: huge = never chunk).  Graphs with few edges chunk earlier: there the pass is as long
+// as its longest list (a 500-slot list is ~30 dependent gather steps of one wave; Arxiv shape: 0.13 -> 0.05 ms per launch)
+static int heavy_slots(int64_t n_edges) {
+    static const int v = [] { const char* e = getenv("GAT_GPL_HEAVY"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 0; }();
+    return v ? v : (n_edges < (16 << 20) ? 128 : kHeavySlotsDefault);
 }
 
 // chunks: {first slot, end slot, partial row index, -}; row = HD floats (BF: HD bf16) per slot
@@ -415,7 +417,7 @@ int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int
 template <int HD, int N, bool BF>
 static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const float* a,
                     float slope, float* gPL, int64_t n_table, const int4* chunks, int32_t n_chunks, const int4* heavy,
-                    int32_t n_heavy, float* part, int wpb, hipStream_t s) {
+                    int32_t n_heavy, float* part, int wpb, int64_t n_slots, hipStream_t s) {
     if (n_heavy > 0) {                                  // long lists first: they are the longest-running waves
         hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, BF>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
                            stash, cdst, gfull, a, slope, part);
@@ -423,7 +425,7 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
         hipLaunchKernelGGL(gpl_heavy_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, heavy, n_heavy, part, gPL, HD);
     }
     hipLaunchKernelGGL((gpl_pull_kernel<HD, N, BF>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
-                       cdst, gfull, a, slope, gPL, n_table, heavy_slots());
+                       cdst, gfull, a, slope, gPL, n_table, heavy_slots(n_slots));
     GAT_HIP(hipGetLastError());
     return 0;
 }
@@ -431,12 +433,11 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
 int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16, const float* a,
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
                     int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, hipStream_t s) {
-    (void)n_slots;
     if (n_table <= 0) return 0;
     static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
     const int HD = H * D;
-#define PULL(HD_, N_) return g_bf16 ? run_pull<HD_, N_, true>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, s) \
-                                     : run_pull<HD_, N_, false>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, s)
+#define PULL(HD_, N_) return g_bf16 ? run_pull<HD_, N_, true>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, s) \
+                                     : run_pull<HD_, N_, false>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, s)
     if (D == 8 && HD == 64) PULL(64, 4);
     if (D == 8 && HD == 32) PULL(32, 4);
     if (D == 4 && HD == 64) PULL(64, 2);
@@ -482,13 +483,14 @@ int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t*
     return rc;
 }
 
-int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, HeavyList* out, hipStream_t s) {
+int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, int64_t n_edges, HeavyList* out, hipStream_t s) {
     out->chunks.clear(); out->heavy.clear();
     if (n_table <= 0) return 0;
     std::vector<int32_t> ptr((size_t)n_table + 1);
     GAT_HIP(hipMemcpyAsync(ptr.data(), d_src_ptr, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     GAT_HIP(hipStreamSynchronize(s));
-    const int kHeavySlots = heavy_slots();
+    const int kHeavySlots = heavy_slots(n_edges);
+    out->threshold = kHeavySlots;
     for (int64_t src = 0; src < n_table; ++src) {
         const int32_t b = ptr[(size_t)src], e = ptr[(size_t)src + 1];
         if (e - b <= kHeavySlots) continue;
@@ -532,10 +534,10 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
     if (msg_bf16) {
         const dim3 grid((unsigned)((n_table + wpb - 1) / wpb)), block(64 * wpb);
         switch (HD) {
-            case 64: hipLaunchKernelGGL(gpl_sum_bf16_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
-            case 32: hipLaunchKernelGGL(gpl_sum_bf16_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
-            case 16: hipLaunchKernelGGL(gpl_sum_bf16_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
-            case 8: hipLaunchKernelGGL(gpl_sum_bf16_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+            case 64: hipLaunchKernelGGL(gpl_sum_bf16_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+            case 32: hipLaunchKernelGGL(gpl_sum_bf16_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+            case 16: hipLaunchKernelGGL(gpl_sum_bf16_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+            case 8: hipLaunchKernelGGL(gpl_sum_bf16_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
             default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
         }
         GAT_HIP(hipGetLastError());
@@ -547,10 +549,10 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
         const int rpi = 64 / (HD / 4);
         const dim3 grid((unsigned)((n_table + 4 * rpi - 1) / (4 * rpi))), block(256);
         switch (HD) {
-            case 64: hipLaunchKernelGGL(gpl_sum_group_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
-            case 32: hipLaunchKernelGGL(gpl_sum_group_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
-            case 16: hipLaunchKernelGGL(gpl_sum_group_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
-            case 8: hipLaunchKernelGGL(gpl_sum_group_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+            case 64: hipLaunchKernelGGL(gpl_sum_group_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+            case 32: hipLaunchKernelGGL(gpl_sum_group_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+            case 16: hipLaunchKernelGGL(gpl_sum_group_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+            case 8: hipLaunchKernelGGL(gpl_sum_group_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
             default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
         }
         GAT_HIP(hipGetLastError());
@@ -558,10 +560,10 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
     }
     const dim3 grid((unsigned)((n_table + wpb - 1) / wpb)), block(64 * wpb);
     switch (HD) {
-        case 64: hipLaunchKernelGGL(gpl_sum_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
-        case 32: hipLaunchKernelGGL(gpl_sum_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
-        case 16: hipLaunchKernelGGL(gpl_sum_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
-        case 8: hipLaunchKernelGGL(gpl_sum_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots()); break;
+        case 64: hipLaunchKernelGGL(gpl_sum_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+        case 32: hipLaunchKernelGGL(gpl_sum_kernel<32>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+        case 16: hipLaunchKernelGGL(gpl_sum_kernel<16>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+        case 8: hipLaunchKernelGGL(gpl_sum_kernel<8>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
         default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
     }
     GAT_HIP(hipGetLastError());

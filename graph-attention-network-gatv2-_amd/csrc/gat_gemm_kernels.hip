@@ -315,6 +315,84 @@ __global__ __launch_bounds__(256) void rowgemm_pipe_kernel(AS as, BS bs, EP ep, 
     }
 }
 
+// ---- projection of FEW rows with a LONG K (Cora-shape: 2,708 x 1,433; Pubmed-shape: 19,717 x 500) ----------------
+// The row-streaming kernel above gives such a product 22 (Cora) or 154 (Pubmed) row tiles for 256 CUs, each walking
+// K in 128-wide chunks one after the other.  Here a block owns 128 rows x 128 columns x ONE 128-wide K chunk (grid.z =
+// K split; its four waves take 32 rows each, as above), and the K partials go to slabs that project_reduce_kernel
+// adds in chunk order (deterministic) on its way through the projection's epilogue.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void project_splitk_kernel(ASrcRows as, BSrcProject bs, float* __restrict__ slabs,
+                                                             int64_t M, int32_t N, int32_t K) {
+    constexpr int NW = 128, NT = 4, KC = 128;
+    extern __shared__ float Bsh[];                    // [KC][NW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.y * NW;
+    const int k0 = blockIdx.z * KC;
+    const int kc = (K - k0 < KC) ? (K - k0) : KC;
+    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + li;
+    float4 af[KC / 8];                                // the wave's A fragments of the chunk: all in flight behind the B fill
+#pragma unroll
+    for (int st = 0; st < KC / 8; ++st) {
+        const int kk = st * 8 + 4 * half;
+        af[st] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < M) {
+            if constexpr (VEC4) {
+                if (kk < kc) af[st] = as.load4(row, k0 + kk);
+            } else {
+                if (kk + 0 < kc) af[st].x = as.load1(row, k0 + kk + 0);
+                if (kk + 1 < kc) af[st].y = as.load1(row, k0 + kk + 1);
+                if (kk + 2 < kc) af[st].z = as.load1(row, k0 + kk + 2);
+                if (kk + 3 < kc) af[st].w = as.load1(row, k0 + kk + 3);
+            }
+        }
+    }
+    for (int idx = threadIdx.x; idx < KC * NW; idx += 256) {       // consecutive threads -> consecutive k (W rows are k-contiguous)
+        const int kk = idx % KC, j = idx / KC;
+        Bsh[kk * NW + j] = (kk < kc && n0 + j < N) ? bs.at(k0 + kk, n0 + j) : 0.f;
+    }
+    __syncthreads();
+    v16f acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < KC / 8; ++st) {
+        const float* brow = Bsh + (st * 8 + 4 * half) * NW + li;
+        const float a4[4] = {af[st].x, af[st].y, af[st].z, af[st].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], brow[j * NW + nt * 32], acc[nt], 0, 0, 0);
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* out = slabs + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t orow = (int64_t)blockIdx.x * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int col = n0 + nt * 32 + li;
+            if (orow < M && col < N) out[orow * N + col] = acc[nt][r];
+        }
+}
+template <class EP>
+__global__ __launch_bounds__(256) void project_reduce_kernel(const float* __restrict__ slabs, int32_t ksplit, int64_t M, int32_t N, EP ep) {
+    const int64_t total = M * N, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        float v = 0.f;
+        for (int z = 0; z < ksplit; ++z) v += slabs[(int64_t)z * total + i];
+        ep(i / N, (int)(i % N), v);
+    }
+}
+// rows few enough that the streaming kernel would leave most CUs idle, K long enough to be worth splitting
+static bool project_wants_splitk(int64_t M, int32_t N, int32_t K) {
+    static const bool off = [] { const char* e = getenv("GAT_PROJECT_SPLITK"); return e && e[0] == '0'; }();     // A/B
+    return !off && K > 128 && ((M + 127) / 128) * ((N + 127) / 128) < 256;
+}
+
 template <class AS, class BS, class EP>
 int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, int32_t K, bool vec4, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -499,13 +577,29 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD) {
+    return project_wants_splitk(n_rows, 2 * HD, F) ? (int64_t)((F + 127) / 128) * n_rows * 2 * HD : 0;
+}
+
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows, int32_t F,
-                   int32_t HD, int32_t part, bool pl_bf16, hipStream_t s) {
+                   int32_t HD, int32_t part, bool pl_bf16, float* scratch, hipStream_t s) {
     const int32_t j0 = part == kPartRight ? HD : 0;
     ASrcRows as{X, F};
     BSrcProject bs{W, F, HD, j0};
     const bool vec4 = (F % 4 == 0) && aligned16(X);
     const int32_t N = part == kPartBoth ? 2 * HD : HD;
+    if (scratch != nullptr && n_rows > 0 && project_wants_splitk(n_rows, N, F)) {
+        const int ksplit = (F + 127) / 128;
+        const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)ksplit);
+        const size_t lds = (size_t)(128 * 128) * sizeof(float);
+        if (vec4) hipLaunchKernelGGL(project_splitk_kernel<true>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+        else hipLaunchKernelGGL(project_splitk_kernel<false>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+        const int64_t rb = std::min<int64_t>((n_rows * N + 255) / 256, 4096);
+        if (pl_bf16) hipLaunchKernelGGL(project_reduce_kernel<EpiProject<true>>, dim3((unsigned)rb), dim3(256), 0, s, scratch, ksplit, n_rows, N, EpiProject<true>{PL_rows, PR, HD, j0});
+        else hipLaunchKernelGGL(project_reduce_kernel<EpiProject<false>>, dim3((unsigned)rb), dim3(256), 0, s, scratch, ksplit, n_rows, N, EpiProject<false>{PL_rows, PR, HD, j0});
+        GAT_HIP(hipGetLastError());
+        return 0;
+    }
     if (pl_bf16) return run_rowgemm(as, bs, EpiProject<true>{PL_rows, PR, HD, j0}, n_rows, N, F, vec4, s);
     return run_rowgemm(as, bs, EpiProject<false>{PL_rows, PR, HD, j0}, n_rows, N, F, vec4, s);
 }

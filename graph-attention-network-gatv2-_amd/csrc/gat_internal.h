@@ -128,8 +128,9 @@ int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t*
 struct HeavyList {
     std::vector<int32_t> chunks;    // int4 {first slot, end slot, partial row, -}
     std::vector<int32_t> heavy;     // int4 {source, first partial, partial count, -}
+    int32_t threshold = 0;          // slots above which a list is chunked (depends on the graph size)
 };
-int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, HeavyList* out, hipStream_t s);
+int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, int64_t n_edges, HeavyList* out, hipStream_t s);
 int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
                    int32_t HD, bool msg_bf16, const int4* chunks, int32_t n_chunks, const int4* heavy,
                    int32_t n_heavy, float* part, hipStream_t s);
@@ -182,8 +183,11 @@ int launch_transpose_nh_to_hn(const float* src_nh, float* dst_hn, int64_t N, int
 // different row sets when the layer input is replicated on every shard (gat_set_source_features).
 enum : int32_t { kPartBoth = 0, kPartLeft = 1, kPartRight = 2 };
 // pl_bf16: PL_rows points at bf16 rows ([.][HD] of 2 bytes) — cfg.storage_dtype
+// scratch: project_scratch_floats(n_rows, F, HD) floats (0 = never needed), or null (then always the streaming kernel);
+// few rows with a long K (Cora / Pubmed shapes) take a split-K path through it
+int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows,
-                   int32_t F, int32_t HD, int32_t part, bool pl_bf16, hipStream_t s);
+                   int32_t F, int32_t HD, int32_t part, bool pl_bf16, float* scratch, hipStream_t s);
 // gradW[j][0:F] += sum_n gPL[n][j] X[n][:],  gradW[j][F:2F] += sum_n gPR[n][j] X[n][:]
 // scratch: at least grad_w_scratch_floats(n_rows, F, HD) floats.
 int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);
