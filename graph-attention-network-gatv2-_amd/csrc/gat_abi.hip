@@ -120,16 +120,19 @@ struct gat_ctx {
     int32_t HDmax = 0, Hmax = 0;
     float* gPL = nullptr; bool gPL_bound = false;   // [n_table][HDmax]
     float* gPR = nullptr;                           // [n_rows][HDmax]
-    float* gH = nullptr;                            // [n_rows][D_last] head-independent output gradient (HeadBwdArgs::gh_out)
+    float* gH = nullptr;                            // [n_rows][gh_stride] head-independent output gradient (HeadBwdArgs::gh_out)
+    int32_t gh_stride = 0;                          // D_last, or 16: 64-B records {gH row | the row's LReLU'(h_pre) decision bytes at +32}
     bool y_valid = false;                           // c->y holds the last forward's probabilities (not after a fused head step)
     int32_t* csc_pos = nullptr;                     // [E] slot of each CSR edge in source-major order
     int32_t* csc_ptr = nullptr;                     // [n_table+1]
     int4* gpl_chunks = nullptr; int4* gpl_heavy = nullptr; float* gpl_part = nullptr;   // long source lists (HeavyList)
+    int4* pull_items = nullptr; int64_t n_pull_items = 0;                               // length-sorted source items of the pull pass
     int32_t n_gpl_chunks = 0, n_gpl_heavy = 0;
     float* msg = nullptr; int32_t msg_hd = 0;       // [E][msg_hd] per-edge message rows (store path)
     uint32_t* stash = nullptr; int32_t stash_words = 0;   // [E][stash_words] per-edge records (stash path: Layer::stash)
     int32_t* csc_dst = nullptr;                     // [E] destination row of every slot (stash path)
     float* gfull = nullptr;                         // [n_rows][HDmax] dL/dh_pre incl. LReLU' (stash path: gathered by the pull pass)
+    uint8_t* hbits = nullptr;                       // [n_rows][HD_last/N] LReLU'(h_pre) decisions of the last layer (EdgeBwdArgs::hbits)
     int32_t dbg = 0;                                // GAT_DBG timing experiments (0 = product behaviour)
     gat::WorkList work;                             // host copy of the item list
     int4* items = nullptr; int4* slot_info = nullptr;
@@ -248,7 +251,15 @@ static int ensure_buffers(gat_ctx* c) {
     }
     if (!c->gPL_bound) GAT_TRY(dalloc(c, &c->gPL, T * c->HDmax));
     GAT_TRY(dalloc(c, &c->gPR, N * c->HDmax));
-    if (!c->cfg.flat_lrelu_index) GAT_TRY(dalloc(c, &c->gH, N * c->layers[L - 1].D));
+    if (!c->cfg.flat_lrelu_index) {
+        // the last layer's pull pass rebuilds g from gH and one decision byte per lane: both in ONE 64-byte record per
+        // node, so that an edge costs one cache line there instead of two (the edge passes are bound by the number of
+        // L1 misses in flight, not by bytes: DESIGN §4)
+        const Layer& yl = c->layers[L - 1];
+        const int w = edge_stash_words(yl.H, yl.D);
+        c->gh_stride = (w > 0 && w <= 32 && yl.D <= 8 && !bf16(c) && !c->cfg.keep_taps) ? 16 : yl.D;
+        GAT_TRY(dalloc(c, &c->gH, N * c->gh_stride));
+    }
     // work items (rows / hub-row segments) of the wave-per-item kernels
     GAT_TRY(dalloc(c, &c->items, std::max<int64_t>(c->work.n_items, 1)));
     GAT_TRY(dalloc(c, &c->slot_info, std::max<int32_t>(c->work.n_slots + c->work.n_split, 1)));
@@ -288,6 +299,7 @@ static int ensure_buffers(gat_ctx* c) {
                 c->stash = reinterpret_cast<uint32_t*>(m); c->stash_words = stash_words;
                 if (msg_hd == 0) { c->msg = m; c->msg_hd = 0; }
                 GAT_TRY(dalloc(c, &c->gfull, N * c->HDmax));
+                if (c->layers[L - 1].stash && c->gH != nullptr && c->gh_stride == 16) c->hbits = reinterpret_cast<uint8_t*>(c->gH) + 32;
                 GAT_TRY(dalloc(c, &c->csc_dst, E));
             }
             GAT_TRY(dalloc(c, &c->csc_pos, E));
@@ -297,6 +309,12 @@ static int ensure_buffers(gat_ctx* c) {
             HeavyList hl;
             GAT_TRY(build_heavy_list(c->csc_ptr, T, E, &hl, c->stream));
             c->n_gpl_chunks = (int32_t)(hl.chunks.size() / 4); c->n_gpl_heavy = (int32_t)(hl.heavy.size() / 4);
+            if (c->stash != nullptr && !hl.items.empty()) {
+                c->n_pull_items = (int64_t)(hl.items.size() / 4);
+                GAT_TRY(dalloc(c, &c->pull_items, c->n_pull_items));
+                GAT_HIP(hipMemcpyAsync(c->pull_items, hl.items.data(), hl.items.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                GAT_HIP(hipStreamSynchronize(c->stream));
+            }
             if (c->n_gpl_heavy > 0) {
                 GAT_TRY(dalloc(c, &c->gpl_chunks, c->n_gpl_chunks));
                 GAT_TRY(dalloc(c, &c->gpl_heavy, c->n_gpl_heavy));
@@ -706,7 +724,7 @@ int gat_head_backward(gat_ctx* c) {
     GAT_TRY(check_layer(c, 0));
     const Layer& y = c->layers.back();
     HeadBwdArgs a{};
-    a.Wo = Wo_of(c); a.HL = y.hout; a.y = c->y; a.labels = c->labels_eff ? c->labels_eff : c->labels; a.hpre = y.hpre; a.g = y.g; a.gh_out = c->gH;
+    a.Wo = Wo_of(c); a.HL = y.hout; a.y = c->y; a.labels = c->labels_eff ? c->labels_eff : c->labels; a.hpre = y.hpre; a.g = y.g; a.gh_out = c->gH; a.gh_stride = c->gh_stride;
     a.gradWo = gWo_of(c); a.partial = c->hb_partial; a.n_rows = c->n_rows; a.C = c->cfg.num_classes;
     a.DL = y.D; a.H = y.H; a.slope = c->cfg.negative_slope; a.flat_index = c->cfg.flat_lrelu_index;
     Scope t(c, GAT_K_HEAD_BWD);
@@ -727,9 +745,13 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.alpha = y.alpha; a.mstat = y.mstat; a.zstat = y.zstat;
     a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge; a.galpha = y.galpha;
     a.g_raw = l < c->cfg.num_layers - 1;           // hidden layers: written by launch_grad_x without the LReLU' factor
-    a.gh = (l == c->cfg.num_layers - 1) ? c->gH : nullptr;
+    a.gh = (l == c->cfg.num_layers - 1) ? c->gH : nullptr; a.gh_stride = c->gh_stride; a.hb_stride = 64;
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
     a.stash = stash ? c->stash : nullptr; a.gfull = stash ? c->gfull : nullptr; a.stash_spare = (uint32_t)c->n_edges;
+    // last layer: the pull pass rebuilds g from gH and the decision bytes (GAT_PULL_LAST=0: gathers gfull like a hidden layer, A/B)
+    static const bool pull_last = [] { const char* e = getenv("GAT_PULL_LAST"); return !(e && e[0] == '0'); }();
+    const bool last_g = stash && a.gh != nullptr && c->hbits != nullptr && !bf16(c) && pull_last;
+    a.hbits = last_g ? c->hbits : nullptr;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots; a.n_split = c->work.n_split;
     a.part_acc = c->part_acc;
     a.dbg = c->dbg;
@@ -743,9 +765,10 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     }
     if (stash) {
         Scope t(c, GAT_K_GPL_SUM);
-        GAT_TRY(launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, bf16(c), a_of(c, l), c->cfg.negative_slope, c->gPL, c->n_table,
+        GAT_TRY(launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, bf16(c), last_g ? c->gH : nullptr, last_g ? c->hbits : nullptr, c->gh_stride, 64,
+                                a_of(c, l), c->cfg.negative_slope, c->gPL, c->n_table,
                                 c->n_edges, y.H, y.D, c->gpl_chunks, c->n_gpl_chunks, c->gpl_heavy, c->n_gpl_heavy, c->gpl_part,
-                                c->stream));
+                                c->pull_items, c->n_pull_items, c->stream));
     } else if (store) {
         Scope t(c, GAT_K_GPL_SUM);
         GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, bf16(c), c->gpl_chunks, c->n_gpl_chunks,
@@ -804,7 +827,7 @@ static void head_args(gat_ctx* c, HeadArgs* f, HeadBwdArgs* b) {
     f->loss_partial = c->loss_partial; f->correct_partial = c->correct_partial;
     f->loss_out = c->loss_out; f->correct_out = c->correct_out;
     f->n_rows = c->n_rows; f->C = c->cfg.num_classes; f->DL = y.D;
-    b->Wo = Wo_of(c); b->HL = y.hout; b->y = c->y; b->labels = c->labels_eff ? c->labels_eff : c->labels; b->hpre = y.hpre; b->g = y.g; b->gh_out = c->gH;
+    b->Wo = Wo_of(c); b->HL = y.hout; b->y = c->y; b->labels = c->labels_eff ? c->labels_eff : c->labels; b->hpre = y.hpre; b->g = y.g; b->gh_out = c->gH; b->gh_stride = c->gh_stride;
     b->gradWo = gWo_of(c); b->partial = c->hb_partial; b->n_rows = c->n_rows; b->C = c->cfg.num_classes;
     b->DL = y.D; b->H = y.H; b->slope = c->cfg.negative_slope; b->flat_index = c->cfg.flat_lrelu_index;
 }
@@ -1111,13 +1134,13 @@ int gat_tap(gat_ctx* c, int tensor, int32_t l, void* host, int64_t count) {
         case GAT_TAP_G: {
             GAT_TRY(need(N * y.HD));
             if (last && c->gH) {                        // formed on the fly by the kernels: same expression, same order
-                std::vector<float> hp((size_t)(N * y.HD)), gh((size_t)(N * y.D));
+                std::vector<float> hp((size_t)(N * y.HD)), gh((size_t)(N * c->gh_stride));
                 GAT_TRY(d2h(c, hp.data(), y.hpre, hp.size() * sizeof(float)));
                 GAT_TRY(d2h(c, gh.data(), c->gH, gh.size() * sizeof(float)));
                 float* out = static_cast<float*>(host);
                 const float inv_heads = 1.0f / (float)y.H;
                 for (int64_t i = 0; i < N * y.HD; ++i)
-                    out[i] = gh[(size_t)((i / y.HD) * y.D + i % y.D)] * (hp[(size_t)i] > 0.f ? 1.0f : c->cfg.negative_slope) * inv_heads;
+                    out[i] = gh[(size_t)((i / y.HD) * c->gh_stride + i % y.D)] * (hp[(size_t)i] > 0.f ? 1.0f : c->cfg.negative_slope) * inv_heads;
                 return 0;
             }
             GAT_TRY(d2h(c, host, y.g, N * y.HD * sizeof(float)));

@@ -283,10 +283,14 @@ template <int N> struct PullVec;
 template <> struct PullVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <> struct PullVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
 
-template <int HD, int N, bool BF>
+// LASTD > 0 (last layer, D = LASTD): g[dst][c] = gh[dst][c % D] * LReLU'(h_pre[dst][c]) / H  (E:598-603) is rebuilt from
+// gh [n_rows][D] and the per-lane decision byte hbits [n_rows][HD/N] — 48 B gathered per edge from two small tables
+// (98 MB + 39 MB at the Products shape: cache-resident) instead of a 256-B row of g.
+template <int HD, int N, bool BF, int LASTD>
 __device__ __forceinline__ typename PullVec<N>::T pull_range(const uint32_t* __restrict__ stash,
                                                              const int32_t* __restrict__ cdst,
-                                                             const float* __restrict__ gfull, int b, int e, int lane,
+                                                             const float* __restrict__ gfull, const uint8_t* __restrict__ hbits, int gh_stride, int hb_stride,
+                                                             float slope, int b, int e, int lane,
                                                              typename PullVec<N>::T ac, typename PullVec<N>::T acs) {
     using V = typename PullVec<N>::T;
     constexpr int LPE = HD / N, G = 64 / LPE;
@@ -311,7 +315,13 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range(const uint32_t* __r
             const int ic = i < e ? i : e - 1;                   // clamped: loads need no predicate
             w[u] = stash[(uint64_t)(uint32_t)ic * LPE + cp];
             const uint32_t drow = (uint32_t)__shfl(dv, u * G + gidx);
-            if constexpr (BF) {                                   // g rows stored as bf16 (cfg.storage_dtype): 2*N bytes per lane
+            if constexpr (LASTD > 0) {                            // gfull = gh here
+                constexpr float inv_heads = 1.0f / (float)(HD / LASTD);
+                const V gh4 = *reinterpret_cast<const V*>(gfull + (size_t)drow * gh_stride + (cp * N) % LASTD);
+                const uint32_t nib = hbits[(size_t)drow * hb_stride + cp];
+#pragma unroll
+                for (int k = 0; k < N; ++k) g[u][k] = gh4[k] * ((nib >> k) & 1u ? 1.0f : slope) * inv_heads;
+            } else if constexpr (BF) {                                   // g rows stored as bf16 (cfg.storage_dtype): 2*N bytes per lane
                 const char* p = reinterpret_cast<const char*>(gfull) + drow * (uint32_t)(HD * 2) + (uint32_t)cp * (uint32_t)(N * 2);
                 if constexpr (N == 2) {
                     const uint32_t w2 = *reinterpret_cast<const uint32_t*>(p);
@@ -347,9 +357,10 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range(const uint32_t* __r
     return acc;
 }
 
-template <int HD, int N, bool BF>
+template <int HD, int N, bool BF, int LASTD>
 __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict__ src_ptr, const uint32_t* __restrict__ stash,
                                                        const int32_t* __restrict__ cdst, const float* __restrict__ gfull,
+                                                       const uint8_t* __restrict__ hbits, int gh_stride, int hb_stride,
                                                        const float* __restrict__ a, float slope, float* __restrict__ gPL,
                                                        int64_t n_table, int32_t kHeavySlots) {
     using V = typename PullVec<N>::T;
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
     V acc;
     if (b < e) {
         const V ac = *reinterpret_cast<const V*>(a + cp * N);
-        acc = pull_range<HD, N, BF>(stash, cdst, gfull, b, e, lane, ac, ac * slope);
+        acc = pull_range<HD, N, BF, LASTD>(stash, cdst, gfull, hbits, gh_stride, hb_stride, slope, b, e, lane, ac, ac * slope);
     } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = 0.f;
@@ -372,10 +383,11 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
     if (lane < LPE) *reinterpret_cast<V*>(gPL + s * HD + cp * N) = acc;
 }
 
-template <int HD, int N, bool BF>
+template <int HD, int N, bool BF, int LASTD>
 __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restrict__ chunks, int32_t n_chunks,
                                                              const uint32_t* __restrict__ stash, const int32_t* __restrict__ cdst,
-                                                             const float* __restrict__ gfull, const float* __restrict__ a,
+                                                             const float* __restrict__ gfull, const uint8_t* __restrict__ hbits,
+                                                             int gh_stride, int hb_stride, const float* __restrict__ a,
                                                              float slope, float* __restrict__ part) {
     using V = typename PullVec<N>::T;
     constexpr int LPE = HD / N;
@@ -386,8 +398,94 @@ __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restr
     const int4 ch = chunks[k];                          // {first slot, end slot, partial row, -}, never empty
     const int cp = lane % LPE;
     const V ac = *reinterpret_cast<const V*>(a + cp * N);
-    const V acc = pull_range<HD, N, BF>(stash, cdst, gfull, ch.x, ch.y, lane, ac, ac * slope);
+    const V acc = pull_range<HD, N, BF, LASTD>(stash, cdst, gfull, hbits, gh_stride, hb_stride, slope, ch.x, ch.y, lane, ac, ac * slope);
     if (lane < LPE) *reinterpret_cast<V*>(part + (int64_t)ch.z * HD + cp * N) = acc;
+}
+
+// Group-per-source form of the same pass (see edge_fwd3_kernel): a wave carries G = 64/(HD/N) source lists side by side,
+// one per lane group, from a length-sorted item list {source, first slot, end slot, partial row | -1} (lists longer than
+// the heavy threshold are cut into chunk items whose partial rows gpl_heavy_fix_kernel adds in chunk order).  One wave
+// per source was latency-bound: four dependent memory latencies per ~25 slots (gathering 48 B instead of 256 B per edge
+// did not change its time).
+template <int HD, int N, bool BF, int LASTD>
+__global__ __launch_bounds__(256) void gpl_pull3_kernel(const int4* __restrict__ items, int64_t n_items,
+                                                        const uint32_t* __restrict__ stash, const int32_t* __restrict__ cdst,
+                                                        const float* __restrict__ gfull, const uint8_t* __restrict__ hbits,
+                                                        int gh_stride, int hb_stride,
+                                                        const float* __restrict__ a, float slope, float* __restrict__ gPL,
+                                                        float* __restrict__ part) {
+    using V = typename PullVec<N>::T;
+    constexpr int LPE = HD / N, G = 64 / LPE, U = 4;
+    static_assert(LPE >= U, "lane layout");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cp = lane % LPE, gidx = lane / LPE;
+    const int64_t it = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * G + gidx;
+    int src = -1, b = 0, e = 0, pslot = -1;
+    if (it < n_items) { const int4 item = items[it]; src = item.x; b = item.y; e = item.z; pslot = item.w; }
+    const V ac = *reinterpret_cast<const V*>(a + cp * N);
+    const V acs = ac * slope;
+    V acc;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = 0.f;
+    int nst = (e - b + U - 1) / U;
+#pragma unroll
+    for (int off = LPE; off < 64; off <<= 1) { const int o = __shfl_xor(nst, off); nst = nst > o ? nst : o; }
+    nst = __builtin_amdgcn_readfirstlane(nst);
+    auto load_dst = [&](int st) {                    // lanes 0..U-1 of the group: the step's destination rows (clamped; slot 0 always exists)
+        int j = b + st * U + (cp & (U - 1));
+        j = j < e ? j : e - 1;
+        return cdst[j > 0 ? j : 0];
+    };
+    int dv = load_dst(0);
+    for (int st = 0; st < nst; ++st) {
+        const int dn = load_dst(st + 1);
+        uint32_t w[U];
+        V g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int j = b + st * U + u;
+            j = j < e ? j : e - 1;
+            j = j > 0 ? j : 0;
+            w[u] = stash[(uint64_t)(uint32_t)j * LPE + cp];
+            const uint32_t drow = (uint32_t)__shfl(dv, gidx * LPE + u);
+            if constexpr (LASTD > 0) {
+                constexpr float inv_heads = 1.0f / (float)(HD / LASTD);
+                const V gh4 = *reinterpret_cast<const V*>(gfull + (size_t)drow * gh_stride + (cp * N) % LASTD);
+                const uint32_t nib = hbits[(size_t)drow * hb_stride + cp];
+#pragma unroll
+                for (int k = 0; k < N; ++k) g[u][k] = gh4[k] * ((nib >> k) & 1u ? 1.0f : slope) * inv_heads;
+            } else if constexpr (BF) {
+                const char* p = reinterpret_cast<const char*>(gfull) + drow * (uint32_t)(HD * 2) + (uint32_t)cp * (uint32_t)(N * 2);
+                if constexpr (N == 2) {
+                    const uint32_t w2 = *reinterpret_cast<const uint32_t*>(p);
+                    g[u][0] = __builtin_bit_cast(float, w2 << 16); g[u][1] = __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+                } else {
+                    const uint2 w2 = *reinterpret_cast<const uint2*>(p);
+                    g[u][0] = __builtin_bit_cast(float, w2.x << 16); g[u][1] = __builtin_bit_cast(float, w2.x & 0xFFFF0000u);
+                    g[u][2] = __builtin_bit_cast(float, w2.y << 16); g[u][3] = __builtin_bit_cast(float, w2.y & 0xFFFF0000u);
+                }
+            } else {
+                const uint32_t off = drow * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4);
+                g[u] = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float val = __builtin_bit_cast(float, w[u] & ~((1u << N) - 1u));
+            const float oth = __shfl_xor(val, 1);               // the head's other lane: alpha <-> ge
+            const float al = (cp & 1) ? oth : val, ge = (cp & 1) ? val : oth;
+            V asel;
+#pragma unroll
+            for (int k = 0; k < N; ++k) asel[k] = (w[u] >> k) & 1u ? ac[k] : acs[k];
+            const float keep = (b + st * U + u < e) ? 1.0f : 0.0f;          // padded slots contribute nothing
+            acc += (g[u] * al + asel * ge) * keep;
+        }
+        dv = dn;
+    }
+    if (src < 0) return;
+    float* dst = pslot < 0 ? gPL + (int64_t)src * HD : part + (int64_t)pslot * HD;
+    *reinterpret_cast<V*>(dst + cp * N) = acc;
 }
 
 // cdst[pos[e]] = row of CSR edge e (binary search in row_ptr, as csr_to_coo_kernel)
@@ -414,37 +512,59 @@ int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int
     return 0;
 }
 
-template <int HD, int N, bool BF>
-static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const float* a,
-                    float slope, float* gPL, int64_t n_table, const int4* chunks, int32_t n_chunks, const int4* heavy,
-                    int32_t n_heavy, float* part, int wpb, int64_t n_slots, hipStream_t s) {
+template <int HD, int N, bool BF, int LASTD>
+static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const uint8_t* hbits,
+                    int gh_stride, int hb_stride, const float* a, float slope, float* gPL, int64_t n_table, const int4* chunks, int32_t n_chunks, const int4* heavy,
+                    int32_t n_heavy, float* part, int wpb, int64_t n_slots, const int4* items, int64_t n_items, hipStream_t s) {
+    // GAT_PULL_GROUPS=1: the group-per-source kernel.  Measured SLOWER on the Products shape (5.8 vs 5.36 ms per step), as was
+    // everything else that shortened this pass's dependency chains or shrank its gathers: see DESIGN §4 (random-row rate)
+    static const bool groups = [] { const char* e = getenv("GAT_PULL_GROUPS"); return e && e[0] == '1'; }();
+    if (items != nullptr && groups) {
+        constexpr int G = 64 / (HD / N);
+        const int64_t quads = (n_items + G - 1) / G;
+        hipLaunchKernelGGL((gpl_pull3_kernel<HD, N, BF, LASTD>), dim3((unsigned)((quads + 3) / 4)), dim3(256), 0, s, items, n_items, stash, cdst,
+                           gfull, hbits, gh_stride, hb_stride, a, slope, gPL, part);
+        if (n_heavy > 0) {
+            const int64_t threads = (int64_t)n_heavy * HD;
+            hipLaunchKernelGGL(gpl_heavy_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, heavy, n_heavy, part, gPL, HD);
+        }
+        GAT_HIP(hipGetLastError());
+        return 0;
+    }
     if (n_heavy > 0) {                                  // long lists first: they are the longest-running waves
-        hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, BF>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
-                           stash, cdst, gfull, a, slope, part);
+        hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, BF, LASTD>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
+                           stash, cdst, gfull, hbits, gh_stride, hb_stride, a, slope, part);
         const int64_t threads = (int64_t)n_heavy * HD;
         hipLaunchKernelGGL(gpl_heavy_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, heavy, n_heavy, part, gPL, HD);
     }
-    hipLaunchKernelGGL((gpl_pull_kernel<HD, N, BF>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
-                       cdst, gfull, a, slope, gPL, n_table, heavy_slots(n_slots));
+    hipLaunchKernelGGL((gpl_pull_kernel<HD, N, BF, LASTD>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
+                       cdst, gfull, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, heavy_slots(n_slots));
     GAT_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16, const float* a,
+int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16,
+                    const float* gh, const uint8_t* hbits, int32_t gh_stride, int32_t hb_stride, const float* a,
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
-                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, hipStream_t s) {
+                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, hipStream_t s) {
     if (n_table <= 0) return 0;
     static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
     const int HD = H * D;
-#define PULL(HD_, N_) return g_bf16 ? run_pull<HD_, N_, true>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, s) \
-                                     : run_pull<HD_, N_, false>(src_ptr, stash, cdst, gfull, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, s)
-    if (D == 8 && HD == 64) PULL(64, 4);
-    if (D == 8 && HD == 32) PULL(32, 4);
-    if (D == 4 && HD == 64) PULL(64, 2);
-    if (D == 4 && HD == 32) PULL(32, 2);
-    if (D == 4 && HD == 16) PULL(16, 2);
-    if (D == 4 && HD == 8) PULL(8, 2);
+    const bool last = gh != nullptr && hbits != nullptr;
+#define PULL_ARGS(G_) src_ptr, stash, cdst, G_, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, items, n_items, s
+#define PULL(HD_, N_, D_)                                                                           \
+    {                                                                                               \
+        if (last) return run_pull<HD_, N_, false, D_>(PULL_ARGS(gh));                               \
+        return g_bf16 ? run_pull<HD_, N_, true, 0>(PULL_ARGS(gfull)) : run_pull<HD_, N_, false, 0>(PULL_ARGS(gfull)); \
+    }
+    if (D == 8 && HD == 64) PULL(64, 4, 8)
+    if (D == 8 && HD == 32) PULL(32, 4, 8)
+    if (D == 4 && HD == 64) PULL(64, 2, 4)
+    if (D == 4 && HD == 32) PULL(32, 2, 4)
+    if (D == 4 && HD == 16) PULL(16, 2, 4)
+    if (D == 4 && HD == 8) PULL(8, 2, 4)
 #undef PULL
+#undef PULL_ARGS
     return fail(GAT_E_UNSUPPORTED, "gpl_pull: no stash path for this (H, D)");
 }
 
@@ -491,14 +611,37 @@ int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, int64_t n_edges,
     GAT_HIP(hipStreamSynchronize(s));
     const int kHeavySlots = heavy_slots(n_edges);
     out->threshold = kHeavySlots;
+    out->items.clear();
     for (int64_t src = 0; src < n_table; ++src) {
         const int32_t b = ptr[(size_t)src], e = ptr[(size_t)src + 1];
         if (e - b <= kHeavySlots) continue;
         const int32_t first = (int32_t)(out->chunks.size() / 4);
         int32_t n = 0;
-        for (int32_t cb = b; cb < e; cb += kHeavySlots, ++n)
+        for (int32_t cb = b; cb < e; cb += kHeavySlots, ++n) {
             out->chunks.insert(out->chunks.end(), {cb, std::min(e, cb + kHeavySlots), first + n, 0});
+            out->items.insert(out->items.end(), {(int32_t)src, cb, std::min(e, cb + kHeavySlots), first + n});    // longest items first
+        }
         out->heavy.insert(out->heavy.end(), {(int32_t)src, first, n, 0});
+    }
+    // the other sources: one item each, sorted by list length (longest first) inside windows of consecutive sources
+    // (counting sort; the group-per-source kernel puts neighbours of the list side by side in one wave)
+    {
+        const int64_t win = 4096;
+        std::vector<int64_t> cnt((size_t)kHeavySlots + 2);
+        for (int64_t s0 = 0; s0 < n_table; s0 += win) {
+            const int64_t s1 = std::min(n_table, s0 + win);
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int64_t sr = s0; sr < s1; ++sr) { const int32_t d = ptr[(size_t)sr + 1] - ptr[(size_t)sr]; if (d <= kHeavySlots) ++cnt[(size_t)(kHeavySlots - d) + 1]; }
+            for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+            const size_t base = out->items.size();
+            out->items.resize(base + 4 * (size_t)cnt.back());
+            for (int64_t sr = s0; sr < s1; ++sr) {
+                const int32_t b = ptr[(size_t)sr], e = ptr[(size_t)sr + 1];
+                if (e - b > kHeavySlots) continue;
+                int32_t* it = &out->items[base + 4 * (size_t)cnt[(size_t)(kHeavySlots - (e - b))]++];
+                it[0] = (int32_t)sr; it[1] = b; it[2] = e; it[3] = -1;
+            }
+        }
     }
     return 0;
 }

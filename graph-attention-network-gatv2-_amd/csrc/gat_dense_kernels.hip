@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void head_backward_kernel(HeadBwdArgs A, int32
         }
         __syncthreads();
         if (A.gh_out != nullptr)
-            for (int q = threadIdx.x; q < rows_here * DL; q += 256) A.gh_out[n0 * DL + q] = s_gh[q];
+            for (int q = threadIdx.x; q < rows_here * DL; q += 256) A.gh_out[(n0 + q / DL) * (A.gh_stride ? A.gh_stride : DL) + q % DL] = s_gh[q];
         if (A.g != nullptr) {
             const float* hp = A.hpre + n0 * hd;
             float* gt = A.g + n0 * hd;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void head_backward2_kernel(HeadBwdArgs A, int3
 #pragma unroll
                     for (int d = 0; d < DL; ++d) acc[d] += s_wo[c * DL + d] * z;
                 }
-                float* out = A.gh_out + (n0 + tid) * DL;
+                float* out = A.gh_out + (n0 + tid) * (A.gh_stride ? A.gh_stride : DL);
 #pragma unroll
                 for (int d = 0; d < DL; ++d) out[d] = acc[d];
             }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void head_step_kernel(HeadArgs F, HeadBwdArgs 
 #pragma unroll
                     for (int d = 0; d < DL; ++d) acc[d] += s_wo[c * DL + d] * z;
                 }
-                float* out = A.gh_out + (n0 + tid) * DL;
+                float* out = A.gh_out + (n0 + tid) * (A.gh_stride ? A.gh_stride : DL);
 #pragma unroll
                 for (int d = 0; d < DL; ++d) out[d] = acc[d];
             }

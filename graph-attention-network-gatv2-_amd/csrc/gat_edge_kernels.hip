@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs A) {
         const int e_end_v = per_lane(e_end);
         const float hp = A.hpre[row * HD + c];
         float g;
-        if (A.gh != nullptr) g = A.gh[row * D + (c % D)] * (hp > 0.f ? 1.0f : A.slope) * (1.0f / (float)(HD / D));   // E:598-603
+        if (A.gh != nullptr) g = A.gh[row * A.gh_stride + (c % D)] * (hp > 0.f ? 1.0f : A.slope) * (1.0f / (float)(HD / D));   // E:598-603
         else {
             g = A.g[row * HD + c];
             if (A.g_raw) g *= hp > 0.f ? 1.0f : A.slope;         // E:888-892 applied by the consumer
@@ -870,7 +870,7 @@ __device__ __forceinline__ void edge_bwd2_body(const EdgeBwdArgs& A) {
         const vnf<N> hp = *reinterpret_cast<const vnf<N>*>(A.hpre + row * HD + c);
         const vnf<N> dsel = select_pos<N>(hp, one, slp);
         vnf<N> g;
-        if (A.gh != nullptr) g = *reinterpret_cast<const vnf<N>*>(A.gh + row * D + (c % D)) * dsel * (1.0f / (float)H);   // E:598-603
+        if (A.gh != nullptr) g = *reinterpret_cast<const vnf<N>*>(A.gh + row * A.gh_stride + (c % D)) * dsel * (1.0f / (float)H);   // E:598-603
         else {
             g = *reinterpret_cast<const vnf<N>*>(A.g + row * HD + c);
             if (A.g_raw) g = g * dsel;                           // E:888-892 applied by the consumer
@@ -881,7 +881,16 @@ __device__ __forceinline__ void edge_bwd2_body(const EdgeBwdArgs& A) {
         const float inv = __builtin_amdgcn_rcpf(A.zstat[row * H + c / D] + 1e-8f);
         vnf<N> gpr = vzero<N>();
         if constexpr (STASH) {                                       // one writer per row: whole rows, or a split row's first segment
-            if (gidx == 0 && (slot < 0 || b == A.row_ptr[row])) *reinterpret_cast<vnf<N>*>(A.gfull + row * HD + c) = g;
+            if (gidx == 0 && (slot < 0 || b == A.row_ptr[row])) {
+                if (A.hbits != nullptr) {                                // last layer: decisions only (see EdgeBwdArgs::hbits)
+                    uint32_t nib = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) nib |= (hp[i] > 0.f ? 1u : 0u) << i;
+                    A.hbits[row * A.hb_stride + cp] = (uint8_t)nib;
+                } else {
+                    *reinterpret_cast<vnf<N>*>(A.gfull + row * HD + c) = g;
+                }
+            }
         }
         // edge indices of a chunk: lane k < 16 holds edge e0+k (clamped into the item: no predicate needed)
         auto load_idx = [&](int e0, int& srcv, int& posv) {
@@ -979,7 +988,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
         for (int i = 0; i < N; ++i) dsel[i] = hp[i] > 0.f ? 1.0f : A.slope;
         vnf<N> g;
-        if (A.gh != nullptr) g = *reinterpret_cast<const vnf<N>*>(A.gh + rowc * D + (c % D)) * dsel * (1.0f / (float)H);   // E:598-603
+        if (A.gh != nullptr) g = *reinterpret_cast<const vnf<N>*>(A.gh + rowc * A.gh_stride + (c % D)) * dsel * (1.0f / (float)H);   // E:598-603
         else {
             g = *reinterpret_cast<const vnf<N>*>(A.g + rowc * HD + c);
             if (A.g_raw) g = g * dsel;               // E:888-892 applied by the consumer
@@ -988,8 +997,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const float dot = group_sum<DL>(hsum<N>(g * hp));
         const float m2 = A.mstat[rowc * H + c / D];
         const float inv = __builtin_amdgcn_rcpf(A.zstat[rowc * H + c / D] + 1e-8f);
-        if (row >= 0 && (slot < 0 || b == A.row_ptr[rowc]))      // one writer per row: whole rows, or a split row's first segment
-            store_row_n<HD, N, BF>(A.gfull, (int)rowc, cp, g);       // bf16 storage: the gathered g table is 2-byte too
+        if (row >= 0 && (slot < 0 || b == A.row_ptr[rowc])) {    // one writer per row: whole rows, or a split row's first segment
+            if (A.hbits != nullptr) {                                // last layer: the decisions only (g = gh * LReLU'(h_pre) / H is rebuilt by the pull pass)
+                uint32_t nib = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) nib |= (hp[i] > 0.f ? 1u : 0u) << i;
+                A.hbits[rowc * A.hb_stride + cp] = (uint8_t)nib;
+            } else {
+                store_row_n<HD, N, BF>(A.gfull, (int)rowc, cp, g);   // bf16 storage: the gathered g table is 2-byte too
+            }
+        }
         vnf<N> gpr = vzero<N>();
         const int nst = wave_max_over_groups<HD, N>((e - b + U - 1) / U);
         // Software pipeline.  vmcnt retires loads AND stores in issue order, so a store issued ahead of a gather makes the
@@ -1148,7 +1165,7 @@ __global__ __launch_bounds__(64) void edge_bwd_generic(EdgeBwdArgs A) {
     const float slope = A.slope;
     for (int ch = lane; ch < HD; ch += 64) s_ga[ch] = 0.f;
     auto gval = [&](int64_t i) {                                  // dL/dh_pre (see EdgeBwdArgs::g_raw)
-        if (A.gh != nullptr) return A.gh[(i / HD) * D + (i % D)] * (A.hpre[i] > 0.f ? 1.0f : slope) * (1.0f / (float)H);
+        if (A.gh != nullptr) return A.gh[(i / HD) * A.gh_stride + (i % D)] * (A.hpre[i] > 0.f ? 1.0f : slope) * (1.0f / (float)H);
         const float gv = A.g[i];
         return A.g_raw ? gv * (A.hpre[i] > 0.f ? 1.0f : slope) : gv;
     };

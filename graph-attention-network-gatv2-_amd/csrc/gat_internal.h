@@ -93,6 +93,11 @@ struct EdgeBwdArgs {
     uint32_t* stash;          // or: [E + 1][HD/N] per-edge records by slot (stash path, see edge_stash_words; launch_gpl_pull)
     uint32_t stash_spare;     // index of the spare record behind the last slot (= E): where padded lanes store
     float* gfull;             // [n_rows][HD] written with the stash path: dL/dh_pre incl. the LReLU' factor (gathered by launch_gpl_pull)
+    int32_t gh_stride;        // floats between consecutive rows of gh (D, or 16 when gh rows and their decision bytes share 64-B records)
+    int32_t hb_stride;        // bytes between consecutive rows of hbits
+    uint8_t* hbits;           // last layer (gh != null), or null: [n_rows][HD/N] one byte per lane = the LReLU'(h_pre) decisions of its
+                              // N channels; written INSTEAD of gfull — the pull pass rebuilds g = gh * LReLU'(h_pre) / H from gh
+                              // (32 B per node at D = 8) and these 16 B instead of gathering a 256-B row of g
     float* gPR;               // [n_rows][HD]   written
     float* ge;                // [E][H] or null (tap)
     float* galpha;            // [E][H] or null (tap, E:646); only with ge
@@ -129,6 +134,7 @@ struct HeavyList {
     std::vector<int32_t> chunks;    // int4 {first slot, end slot, partial row, -}
     std::vector<int32_t> heavy;     // int4 {source, first partial, partial count, -}
     int32_t threshold = 0;          // slots above which a list is chunked (depends on the graph size)
+    std::vector<int32_t> items;     // int4 {source, first slot, end slot, partial row | -1}: chunks first, then the other sources by length
 };
 int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, int64_t n_edges, HeavyList* out, hipStream_t s);
 int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
@@ -137,9 +143,11 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
 // cdst[pos[e]] = destination row of CSR edge e (the source-major twin of a1's dst array; built once per graph)
 int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int64_t n_rows, int64_t n_edges, hipStream_t s);
 // Stash path: gPL[s][:] = sum over the slots of s of  g[cdst][:] * alpha + ge * a (.) LReLU'  rebuilt from the records
-int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16, const float* a,
+// gh / hbits non-null (last layer): g rows are rebuilt from gh [n_rows][D] and the per-lane decision bytes instead of read from gfull
+int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16,
+                    const float* gh, const uint8_t* hbits, int32_t gh_stride, int32_t hb_stride, const float* a,
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
-                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, hipStream_t s);
+                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, hipStream_t s);
 
 int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);
@@ -222,6 +230,7 @@ struct HeadBwdArgs {
     float* g;                 // [n_rows][H][DL], or null: only gh_out is written and the edge backward of the last
                               // layer expands it (EdgeBwdArgs::gh) — saves writing 4*N*H*D and reading h_pre here
     float* gh_out;            // [n_rows][DL]  Wo^T dz  (the head-independent part of g), or null
+    int32_t gh_stride;        // floats between consecutive rows of gh_out (0 = DL)
     float* gradWo;            // [C][DL] added into
     float* partial;           // [head_bwd_blocks][C*DL]
     int64_t n_rows;
