@@ -48,6 +48,7 @@ class _Config(C.Structure):
 # enums of the header
 PARAM_W, PARAM_A, PARAM_WO = 0, 1, 2
 TABLE_PL, TABLE_GPL = 0, 1
+COMM_GPL_BF16 = 1
 (TAP_SRC, TAP_DST, TAP_ALPHA, TAP_HPRE, TAP_HOUT, TAP_Y, TAP_G, TAP_GE, TAP_MAX, TAP_SUM, TAP_PL,
  TAP_PR, TAP_SCORE, TAP_GALPHA, TAP_GX) = range(15)
 (K_PROJECT, K_EDGE_FWD, K_HEAD_FWD, K_HEAD_BWD, K_EDGE_BWD, K_GPL_SUM, K_GRAD_W, K_GRAD_X, K_MISC,
@@ -128,6 +129,7 @@ def _declare(lib: C.CDLL) -> None:
         "gat_comm_unique_id": [vp],
         "gat_comm_init_rccl": [vp, i32, i32, vp],
         "gat_comm_init_host": [vp, i32, i32, C.c_char_p, i64],
+        "gat_comm_option": [vp, i32, i32],
         "gat_step": [vp, P(f32), P(i32)],
         "gat_step_graph": [vp, i32],
         "gat_forward": [vp, P(f32), P(i32)],
@@ -370,6 +372,9 @@ class GatContext:
 
     def comm_init_host(self, world: int, rank: int, shm_name: str, bytes_per_rank: int):
         _chk(self.lib.gat_comm_init_host(self._ctx, world, rank, shm_name.encode(), bytes_per_rank))
+
+    def comm_option(self, option: int, value: int):
+        _chk(self.lib.gat_comm_option(self._ctx, option, value))
 
     def zero_grad(self):
         _chk(self.lib.gat_zero_grad(self._ctx))

@@ -111,6 +111,7 @@ struct gat_ctx {
     float* params = nullptr;   // [W | a | Wo]
     float* grads = nullptr;    // [gradW | grada | gradWo] + 4 floats of tail: [loss, correct lo, correct hi, -]
     std::unique_ptr<gat::Comm> comm;                // exchange transport of a shard (gat_comm_init_*)
+    bool comm_gpl_bf16 = false;                     // gat_comm_option(GAT_COMM_GPL_BF16): remote gPL partials travel as bf16
     float* grads_prev = nullptr;                    // [n_params] with a transport: what the buffer held before this step (see reduce_begin)
     // gat_step as a replayed hipGraph (gat_step_graph): 0 off, 1 armed (next step runs eagerly, then captures), 2 ready
     int graph_state = 0, graph_warm = 0;
@@ -851,7 +852,8 @@ static int backward_phases(gat_ctx* c, bool head_done = false) {
         GAT_TRY(gat_layer_backward_edges(c, l));
         if (c->comm && needs_exchange(c, l)) {
             Scope t(c, GAT_K_EXCHANGE);
-            GAT_TRY(c->comm->reduce_scatter(c->gPL, table_slice(c, c->layers[l]), c->stream));
+            if (c->comm_gpl_bf16) GAT_TRY(c->comm->reduce_scatter_bf16(c->gPL, table_slice(c, c->layers[l]), c->stream));
+            else GAT_TRY(c->comm->reduce_scatter(c->gPL, table_slice(c, c->layers[l]), c->stream));
         }
         GAT_TRY(gat_layer_backward_dense(c, l));
     }
@@ -1007,6 +1009,11 @@ int gat_comm_init_host(gat_ctx* c, int32_t world, int32_t rank, const char* shm_
     GAT_TRY(comm_create_host(world, rank, shm_name, bytes_per_rank, &cm));
     c->comm.reset(cm);
     return 0;
+}
+int gat_comm_option(gat_ctx* c, int32_t option, int32_t value) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    if (option == GAT_COMM_GPL_BF16) { c->comm_gpl_bf16 = value != 0; return 0; }
+    return fail(GAT_E_INVALID, "gat_comm_option: unknown option");
 }
 int gat_zero_grad(gat_ctx* c) {
     if (!c) return fail(GAT_E_INVALID, "null context");

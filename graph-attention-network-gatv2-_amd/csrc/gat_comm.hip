@@ -32,11 +32,43 @@ Comm::~Comm() {}
 
 namespace {
 
+// ---- bf16 travel format of the gPL reduce-scatter ---------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, src[i]);
+        dst[i] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
+}
+// own[i] = sum over ranks q in ascending order of (q == rank ? own[i] (fp32) : bf16 recv[q][i])
+__global__ __launch_bounds__(256) void sum_arrivals_kernel(float* __restrict__ own, const uint16_t* __restrict__ recv, int world, int rank,
+                                                           int64_t slice) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slice; i += stride) {
+        float acc = 0.f;
+        for (int q = 0; q < world; ++q)
+            acc += q == rank ? own[i] : __builtin_bit_cast(float, (uint32_t)recv[(int64_t)q * slice + i] << 16);
+        own[i] = acc;
+    }
+}
+static int launch_pack_bf16(const float* src, uint16_t* dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, s, src, dst, n);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+static int launch_sum_arrivals(float* own, const uint16_t* recv, int world, int rank, int64_t slice, hipStream_t s) {
+    if (slice <= 0) return 0;
+    hipLaunchKernelGGL(sum_arrivals_kernel, dim3((unsigned)std::min<int64_t>((slice + 255) / 256, 8192)), dim3(256), 0, s, own, recv, world, rank, slice);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- RCCL (types restated from the public NCCL API; resolved at run time) ------------------------------
 typedef struct ncclComm* ncclComm_t;
 struct ncclUniqueId { char internal[128]; };
 static_assert(sizeof(ncclUniqueId) == GAT_COMM_ID_BYTES, "unique id size");
-enum { kNcclSuccess = 0, kNcclFloat32 = 7, kNcclSum = 0 };
+enum { kNcclSuccess = 0, kNcclInt8 = 0, kNcclFloat32 = 7, kNcclSum = 0 };
 
 struct RcclApi {
     void* h = nullptr;
@@ -46,6 +78,10 @@ struct RcclApi {
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -69,6 +105,10 @@ int load_rccl(RcclApi** out) {
             api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
             api.ReduceScatter = (decltype(api.ReduceScatter))sym("ncclReduceScatter");
             api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+            api.Send = (decltype(api.Send))sym("ncclSend");
+            api.Recv = (decltype(api.Recv))sym("ncclRecv");
+            api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+            api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
             api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
             state = ok ? 1 : -1;
         }
@@ -87,7 +127,6 @@ int load_rccl(RcclApi** out) {
 struct RcclComm final : Comm {
     RcclApi* api = nullptr;
     ncclComm_t comm = nullptr;
-    ~RcclComm() override { if (comm) (void)api->CommDestroy(comm); }
     int all_gather(float* table, int64_t slice, hipStream_t s) override {
         // in place: sendbuff == recvbuff + rank * sendcount
         GAT_NCCL(api, api->AllGather(table + (int64_t)rank * slice, table, (size_t)slice, kNcclFloat32, comm, s));
@@ -101,6 +140,30 @@ struct RcclComm final : Comm {
     int all_reduce(float* buf, int64_t n, hipStream_t s) override {
         GAT_NCCL(api, api->AllReduce(buf, buf, (size_t)n, kNcclFloat32, kNcclSum, comm, s));
         return 0;
+    }
+    // bf16 travel format: one point-to-point send + receive per peer (xGMI is a full mesh: every pair has its own link),
+    // bytes typed as int8 so that no RCCL reduction is involved; the fp32 sum happens on arrival (sum_arrivals_kernel)
+    uint16_t* stage = nullptr; int64_t stage_elems = 0;           // [2][world][slice]: packed outgoing table | arrivals
+    ~RcclComm() override { if (comm) (void)api->CommDestroy(comm); if (stage) (void)hipFree(stage); }
+    int reduce_scatter_bf16(float* table, int64_t slice, hipStream_t s) override {
+        const int64_t need = 2 * (int64_t)world * slice;
+        if (need > stage_elems) {
+            GAT_HIP(hipStreamSynchronize(s));
+            if (stage) (void)hipFree(stage);
+            stage = nullptr; stage_elems = 0;
+            GAT_HIP(hipMalloc((void**)&stage, (size_t)need * sizeof(uint16_t)));
+            stage_elems = need;
+        }
+        uint16_t* out = stage; uint16_t* in = stage + (int64_t)world * slice;
+        GAT_TRY(launch_pack_bf16(table, out, (int64_t)world * slice, s));
+        GAT_NCCL(api, api->GroupStart());
+        for (int q = 0; q < world; ++q) {
+            if (q == rank) continue;
+            GAT_NCCL(api, api->Send(out + (int64_t)q * slice, (size_t)slice * 2, kNcclInt8, q, comm, s));
+            GAT_NCCL(api, api->Recv(in + (int64_t)q * slice, (size_t)slice * 2, kNcclInt8, q, comm, s));
+        }
+        GAT_NCCL(api, api->GroupEnd());
+        return launch_sum_arrivals(table + (int64_t)rank * slice, in, world, rank, slice, s);
     }
 };
 
@@ -132,6 +195,7 @@ struct HostComm final : Comm {
     ShmHeader* hdr() const { return reinterpret_cast<ShmHeader*>(base); }
     float* area(int p) const { return reinterpret_cast<float*>(base + kShmHeader + (size_t)p * bytes_per_rank); }
     ~HostComm() override {
+        if (dstage) (void)hipFree(dstage);
         if (base) munmap(base, total);
         if (rank == 0 && !name.empty()) shm_unlink(name.c_str());
     }
@@ -195,6 +259,41 @@ struct HostComm final : Comm {
         GAT_TRY(meet());
         GAT_TRY(sum_into_tmp((int64_t)rank * slice, slice));
         GAT_HIP(hipMemcpyAsync(table + (int64_t)rank * slice, tmp.data(), slice * sizeof(float), hipMemcpyHostToDevice, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        return meet();
+    }
+    // the same travel format through the segment: every rank publishes its whole table rounded to bf16, then adds the
+    // other ranks' versions of ITS slice to its own fp32 partial, in ascending rank order (what sum_arrivals_kernel does)
+    uint16_t* dstage = nullptr; int64_t dstage_elems = 0;
+    std::vector<uint16_t> hstage;
+    int reduce_scatter_bf16(float* table, int64_t slice, hipStream_t s) override {
+        const int64_t n = slice * world;
+        GAT_TRY(fits((n + 1) / 2));
+        if (n > dstage_elems) {
+            GAT_HIP(hipStreamSynchronize(s));
+            if (dstage) (void)hipFree(dstage);
+            dstage = nullptr; dstage_elems = 0;
+            GAT_HIP(hipMalloc((void**)&dstage, (size_t)n * sizeof(uint16_t)));
+            dstage_elems = n;
+        }
+        GAT_TRY(launch_pack_bf16(table, dstage, n, s));
+        GAT_HIP(hipMemcpyAsync(area(rank), dstage, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost, s));
+        tmp.resize((size_t)slice);
+        GAT_HIP(hipMemcpyAsync(tmp.data(), table + (int64_t)rank * slice, (size_t)slice * sizeof(float), hipMemcpyDeviceToHost, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        GAT_TRY(meet());
+        std::vector<float> own(tmp);
+        for (int64_t i = 0; i < slice; ++i) {
+            float acc = 0.f;
+            for (int q = 0; q < world; ++q) {
+                if (q == rank) { acc += own[(size_t)i]; continue; }
+                const uint32_t u = (uint32_t)reinterpret_cast<const uint16_t*>(area(q))[(int64_t)rank * slice + i] << 16;
+                float f; memcpy(&f, &u, sizeof(f));
+                acc += f;
+            }
+            tmp[(size_t)i] = acc;
+        }
+        GAT_HIP(hipMemcpyAsync(table + (int64_t)rank * slice, tmp.data(), (size_t)slice * sizeof(float), hipMemcpyHostToDevice, s));
         GAT_HIP(hipStreamSynchronize(s));
         return meet();
     }

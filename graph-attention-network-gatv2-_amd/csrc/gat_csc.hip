@@ -518,7 +518,10 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
                     int32_t n_heavy, float* part, int wpb, int64_t n_slots, const int4* items, int64_t n_items, hipStream_t s) {
     // GAT_PULL_GROUPS=1: the group-per-source kernel.  Measured SLOWER on the Products shape (5.8 vs 5.36 ms per step), as was
     // everything else that shortened this pass's dependency chains or shrank its gathers: see DESIGN §4 (random-row rate)
-    static const bool groups = [] { const char* e = getenv("GAT_PULL_GROUPS"); return e && e[0] == '1'; }();
+    static const int groups_env = [] { const char* e = getenv("GAT_PULL_GROUPS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    // default: groups only where the lists are short (a destination-range shard sees ~deg/P slots per source: one wave
+    // per 3-slot list wastes 15 of its 16 gather slots) — the same rule the message-row sum used (n_slots < 8 n_table)
+    const bool groups = groups_env >= 0 ? groups_env == 1 : n_slots < 8 * n_table;
     if (items != nullptr && groups) {
         constexpr int G = 64 / (HD / N);
         const int64_t quads = (n_items + G - 1) / G;

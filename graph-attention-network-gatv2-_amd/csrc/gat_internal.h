@@ -160,6 +160,10 @@ struct Comm {
     // table: [world][slice] floats; the rank's slice already written / afterwards holding the sum
     virtual int all_gather(float* table, int64_t slice, hipStream_t s) = 0;
     virtual int reduce_scatter(float* table, int64_t slice, hipStream_t s) = 0;
+    // The same exchange with the REMOTE partial sums travelling as bf16 (half the xGMI volume): every rank rounds the
+    // slices it sends to bf16 (nearest even), keeps its own partial in fp32, and adds what arrives in fp32 in ascending
+    // rank order.  Option GAT_COMM_GPL_BF16; relative error of the summed rows ~ 2^-9 per remote term.
+    virtual int reduce_scatter_bf16(float* table, int64_t slice, hipStream_t s) = 0;
     virtual int all_reduce(float* buf, int64_t n, hipStream_t s) = 0;
 };
 int comm_unique_id(void* id_out);

@@ -163,6 +163,13 @@ int gat_layer_exchange(gat_ctx* ctx, int32_t layer, int32_t* needed);
 int gat_comm_unique_id(void* id_out);
 int gat_comm_init_rccl(gat_ctx* ctx, int32_t world, int32_t rank, const void* id);
 int gat_comm_init_host(gat_ctx* ctx, int32_t world, int32_t rank, const char* shm_name, int64_t bytes_per_rank);
+/* Options of the exchanges run by the library (any transport).
+ *   GAT_COMM_GPL_BF16 = 1: in the gPL reduce-scatter the REMOTE partial sums travel as bf16 (half the xGMI volume of the
+ *   backward exchange); each rank keeps its own partial in fp32 and adds the arrivals in fp32, in ascending rank order.
+ *   Default 0 (fp32 on the wire).  Gradients then differ from the fp32 exchange by ~2^-9 relative per remote term: the
+ *   parity bar of this mode is 1e-2 (like bf16 storage). */
+enum { GAT_COMM_GPL_BF16 = 1 };
+int gat_comm_option(gat_ctx* ctx, int32_t option, int32_t value);
 /* forward + backward without a host round-trip in between; with a transport the loss and #correct
  * ride in the tail of the gradient all-reduce.  Returns the global loss sum / #correct. */
 int gat_step(gat_ctx* ctx, float* loss_sum, int32_t* n_correct);

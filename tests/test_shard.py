@@ -367,6 +367,13 @@ def test_library_transport_rccl_world1(pkg, orc):
     loss, correct = ctx.step()
     grads = np.concatenate([ctx.grads_get(g) for g in range(3)])
     launches = ctx.kernel_stats()["exchange"][0]
+    # the bf16 travel format of the gPL reduce-scatter through RCCL's grouped send/recv path: at world 1 nothing is
+    # remote, the own partial stays fp32 => bitwise the fp32 exchange
+    ctx.comm_option(pkg.abi.COMM_GPL_BF16, 1)
+    ctx.zero_grad()
+    loss_b, correct_b = ctx.step()
+    assert (loss_b, correct_b) == (loss, correct)
+    assert np.array_equal(np.concatenate([ctx.grads_get(g) for g in range(3)]), grads)
     ctx.close()
     assert launches == 2 + 2 + 1             # all-gather and reduce-scatter per layer, one all-reduce
     assert abs(loss - ref.loss_sum_f64) < 1e-4 * P["n"] and correct == ref.n_correct
@@ -423,3 +430,48 @@ def test_dead_peer_makes_the_other_ranks_fail_not_hang(pkg):
         outs = [open(os.path.join(d, f"r{r}.txt")).read().splitlines() for r in range(world - 1)]
     for secs, msg in outs:
         assert float(secs) < 30.0 and "host transport" in msg and ("did not arrive" in msg or "gave up" in msg), (secs, msg)
+
+
+def _bf16_rs_worker(rank, world, outdir, shm):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as entry
+    pkg = entry.load_package(); orc = entry.load_oracle()
+    P = _problem()
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    W, a, Wo = orc.xavier_params(cfg, 11)
+    S = pkg.shard
+    plan = S.make_plan(P["rp"], world, rank)
+    rp_l, ci_l = S.local_csr(plan, P["rp"], P["ci"])
+    lo, hi = plan.row0, plan.row0 + plan.n_rows
+    out = {}
+    for mode in (0, 1):
+        ctx = pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"], device=0)
+        ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
+        ctx.set_features(P["x"][lo:hi])                 # layer 0 exchanged too: two bf16 reduce-scatters per step
+        ctx.set_labels(P["lab"][lo:hi])
+        for g, arr in enumerate((W, a, Wo)):
+            ctx.params_set(g, arr)
+        ctx.comm_init_host(world, rank, f"{shm}_{mode}", 4 * max(plan.n_table * 64, ctx.n_params + 3))
+        ctx.comm_option(pkg.abi.COMM_GPL_BF16, mode)
+        ctx.zero_grad()
+        loss, correct = ctx.step()
+        out[f"g{mode}"] = np.concatenate([ctx.grads_get(g) for g in range(3)]); out[f"l{mode}"] = loss
+        ctx.close()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), **out)
+
+
+@pytest.mark.gpu
+def test_bf16_gpl_reduce_scatter_option(pkg):
+    """GAT_COMM_GPL_BF16: remote gPL partials travel as bf16, fp32 accumulate on arrival in rank order.  The forward
+    is untouched (same loss); gradients agree with the fp32 exchange within 1e-2 of their max-abs (the mode's bar,
+    like bf16 storage) but are NOT identical (the option really changes the wire format); all ranks hold the same sums."""
+    import torch.multiprocessing as mp
+    world = 3
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_bf16_rs_worker, args=(world, d, f"/gatv2_bf16rs_{os.getpid()}"), nprocs=world, join=True)
+        outs = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
+    for o in outs:
+        assert float(o["l0"]) == float(o["l1"])
+        parity.check_rel("bf16 gPL exchange vs fp32 exchange", o["g1"], o["g0"], 1e-2)
+        assert not np.array_equal(o["g1"], o["g0"])
+        assert np.array_equal(o["g1"], outs[0]["g1"])
