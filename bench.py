@@ -331,7 +331,11 @@ def main():
                               "traffic_over_algorithmic": (step_traffic / bytes_step_all) if step_traffic else None},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world, dom),
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch_bytes} if timed else None,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
+                         # the kernel's REAL HBM rate (PMC bytes / measured time): what the memory system delivers to it,
+                         # whatever share of those bytes the algorithm needs
+                         "achieved_traffic_GBps": (measured_traffic(args, world, dom) / (avg_ms * 1e-3) / 1e9)
+                                                  if measured_traffic(args, world, dom) else None} if timed else None,
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in stats.items() if v[0] > 0},
         }
         if not args.no_cpu_baseline and world == 1:      # CPU lines: rank 0 at N = 1 only (the other ranks would wait in the barrier)

@@ -103,6 +103,7 @@ struct gat_ctx {
     bool have_graph = false, have_x = false, have_labels = false, buffers_ready = false;
     int32_t* row_ptr = nullptr; int32_t* col_idx = nullptr; int32_t* labels = nullptr;
     int32_t* labels_eff = nullptr;                  // with a training mask: label, or ~label outside the mask (gat_set_train_mask)
+    int32_t* labels_eff_buf = nullptr;              // its storage (labels_eff is null while no mask is set)
     uint8_t* mask_tmp = nullptr;                    // [n_rows] device copy of the mask of the last gat_set_train_mask / gat_eval_mask
     double* eval_loss = nullptr; int32_t* eval_cnt = nullptr;      // block partials of gat_eval_mask
     float* X0 = nullptr;
@@ -551,11 +552,10 @@ int gat_set_train_mask(gat_ctx* c, const uint8_t* mask, int64_t n_rows) {
         return 0;
     }
     GAT_TRY(upload_mask(c, mask, n_rows));
-    int32_t* eff = nullptr;
-    GAT_TRY(dalloc(c, &eff, n_rows));
-    GAT_TRY(launch_apply_mask(c->labels, c->mask_tmp, eff, n_rows, c->stream));
+    if (!c->labels_eff_buf) GAT_TRY(dalloc(c, &c->labels_eff_buf, n_rows));      // one buffer, reused by later calls
+    GAT_TRY(launch_apply_mask(c->labels, c->mask_tmp, c->labels_eff_buf, n_rows, c->stream));
     GAT_HIP(hipStreamSynchronize(c->stream));
-    c->labels_eff = eff;
+    c->labels_eff = c->labels_eff_buf;
     graph_drop_fwd(c);                              // a captured step holds the old label pointer
     return 0;
 }
@@ -1246,6 +1246,12 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     hipStream_t s = (hipStream_t)stream;
     const int HD = h * d;
     TmpBufs t;
+    if (!d_col_idx) {                  // e == 0: the kernels still clamp their index prefetch to edge 0 — give them one to read
+        float* dummy = nullptr;
+        GAT_TRY(t.get(&dummy, 1));
+        GAT_HIP(hipMemsetAsync(dummy, 0, sizeof(float), s));
+        d_col_idx = reinterpret_cast<const int32_t*>(dummy);
+    }
     float *PL, *PR, *alpha, *gPL, *gPR, *gap, *scr;
     const int blocks = 2048;      // capacity; the grid actually used is computed below
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));

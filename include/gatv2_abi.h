@@ -79,7 +79,10 @@ int gat_mem_info(size_t* free_bytes, size_t* total_bytes);   /* cudaMemGetInfo, 
  * ids (see INTEGRATION.md "sharding"); host arrays are copied. */
 /* Limits: n_edges, n_rows and n_table must each fit int32 (the reference's CSR is int32 too, E:1045-1046; the
  * one-time source-major index is built with a 32-bit-count radix sort) — larger graphs are refused with
- * GAT_E_UNSUPPORTED, never truncated.  Offsets INTO tensors are 64-bit everywhere. */
+ * GAT_E_UNSUPPORTED, never truncated.  Offsets INTO tensors are 64-bit everywhere.  The wave-per-row kernels
+ * address the gathered PL table as base + 32-bit byte offset: a table of 4 GiB or more (n_table * H*D * 4 bytes, i.e.
+ * > 16.7 M rows at H*D = 64) runs on the generic kernels instead — same results, float atomics, several times slower
+ * (no BASELINE config is that large per GPU; bf16 storage is refused there). */
 int gat_set_graph(gat_ctx* ctx, const int32_t* row_ptr, const int32_t* col_idx, int64_t n_rows,
                   int64_t n_edges, int64_t n_table, int64_t table_row0);
 int gat_set_features(gat_ctx* ctx, const float* x, int64_t n_rows, int32_t in_dim);   /* [n_rows][F0] */
