@@ -333,7 +333,11 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range(const uint32_t* __r
                 }
             } else {
                 const uint32_t off = drow * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4);
+#ifdef GAT_NT_GATHER
+                g[u] = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + off));
+#else
                 g[u] = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + off);
+#endif
             }
         }
 #pragma unroll
@@ -467,7 +471,11 @@ __global__ __launch_bounds__(256) void gpl_pull3_kernel(const int4* __restrict__
                 }
             } else {
                 const uint32_t off = drow * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4);
+#ifdef GAT_NT_GATHER
+                g[u] = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + off));
+#else
                 g[u] = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + off);
+#endif
             }
         }
 #pragma unroll

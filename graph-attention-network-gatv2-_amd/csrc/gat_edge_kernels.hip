@@ -552,7 +552,11 @@ __device__ __forceinline__ vnf<N> gather_row_n(const float* __restrict__ table, 
         return r;
     } else {
         const uint32_t off = (uint32_t)row * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4);
+#ifdef GAT_NT_GATHER      // experiment: gathered rows are used once by one wave — non-temporal policy
+        return __builtin_nontemporal_load(reinterpret_cast<const vnf<N>*>(reinterpret_cast<const char*>(table) + off));
+#else
         return *reinterpret_cast<const vnf<N>*>(reinterpret_cast<const char*>(table) + off);
+#endif
     }
 }
 template <int HD, int N, bool BF>
