@@ -59,6 +59,10 @@ def parse():
                     help="N>1 exchanges: 'native' = RCCL called by the library on the context's stream (in-place "
                          "all-gather / reduce-scatter, one all-reduce); 'torch' = the same plan driven from "
                          "shard.ShardedGat over torch.distributed")
+    ap.add_argument("--comm-chunks", type=int, default=1,
+                    help="N>1, --comm native: chunk-pipelined forward exchange (gat_comm_option GAT_COMM_PIPELINE); results unchanged")
+    ap.add_argument("--gpl-bf16", action="store_true",
+                    help="N>1, --comm native: remote gPL partial sums travel as bf16 (GAT_COMM_GPL_BF16; 1e-2 parity mode, NOT the headline)")
     ap.add_argument("--beta", type=float, default=0.75, help="power-law exponent of the degree law (debug)")
     return ap.parse_args()
 
@@ -233,6 +237,10 @@ def main():
                     idt.copy_(torch.frombuffer(bytearray(pkg.GatContext.comm_unique_id()), dtype=torch.uint8))
                 dist.broadcast(idt, 0)
                 ctx.comm_init_rccl(world, rank, bytes(idt.cpu().tolist()))
+                if args.comm_chunks > 1:
+                    ctx.comm_option(A.COMM_PIPELINE, args.comm_chunks)
+                if args.gpl_bf16:
+                    ctx.comm_option(A.COMM_GPL_BF16, 1)
                 runner = ctx
             else:
                 runner = S.ShardedGat(ctx, plan, S.TorchComm(), heads, outdims,
@@ -317,7 +325,9 @@ def main():
                             + ("fp32" if args.dtype == "f32" else "fp32 arithmetic / bf16 PL+message storage"),
                 "launch": "hipGraph replay" if use_graph else "eager",
                 "parallelism": (f"dst-range x{world}, " + ("all layers exchanged" if args.exchange_layer0 else
-                                "input features replicated (layer 0 exchange-free)") + f", exchanges: {comm_kind}")
+                                "input features replicated (layer 0 exchange-free)") + f", exchanges: {comm_kind}"
+                                + (f", forward exchange pipelined in {args.comm_chunks} chunks" if args.comm_chunks > 1 else "")
+                                + (", remote gPL partials as bf16" if args.gpl_bf16 else ""))
                                if runner is not None else "single GPU",
                 "loss_per_node": loss / n, "setup_s": round(t_gen, 1), "index_s": round(t_up, 2),
                 "generator": "device (csrc/gat_synth.hip), bit-for-bit synth.py",

@@ -49,6 +49,7 @@ class _Config(C.Structure):
 PARAM_W, PARAM_A, PARAM_WO = 0, 1, 2
 TABLE_PL, TABLE_GPL = 0, 1
 COMM_GPL_BF16 = 1
+COMM_PIPELINE = 2
 (TAP_SRC, TAP_DST, TAP_ALPHA, TAP_HPRE, TAP_HOUT, TAP_Y, TAP_G, TAP_GE, TAP_MAX, TAP_SUM, TAP_PL,
  TAP_PR, TAP_SCORE, TAP_GALPHA, TAP_GX) = range(15)
 (K_PROJECT, K_EDGE_FWD, K_HEAD_FWD, K_HEAD_BWD, K_EDGE_BWD, K_GPL_SUM, K_GRAD_W, K_GRAD_X, K_MISC,

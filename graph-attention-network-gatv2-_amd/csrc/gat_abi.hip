@@ -112,6 +112,9 @@ struct gat_ctx {
     float* params = nullptr;   // [W | a | Wo]
     float* grads = nullptr;    // [gradW | grada | gradWo] + 4 floats of tail: [loss, correct lo, correct hi, -]
     std::unique_ptr<gat::Comm> comm;                // exchange transport of a shard (gat_comm_init_*)
+    int32_t comm_chunks = 1;                        // gat_comm_option(GAT_COMM_PIPELINE): row chunks of the pipelined forward exchange
+    hipStream_t comm_stream = nullptr;              // second stream of the pipelined exchange (created on first use)
+    std::vector<hipEvent_t> comm_events;
     bool comm_gpl_bf16 = false;                     // gat_comm_option(GAT_COMM_GPL_BF16): remote gPL partials travel as bf16
     float* grads_prev = nullptr;                    // [n_params] with a transport: what the buffer held before this step (see reduce_begin)
     // gat_step as a replayed hipGraph (gat_step_graph): 0 off, 1 armed (next step runs eagerly, then captures), 2 ready
@@ -420,6 +423,8 @@ int gat_destroy(gat_ctx* c) {
     for (auto& p : c->ev_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     c->comm.reset();
+    for (hipEvent_t e : c->comm_events) (void)hipEventDestroy(e);
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     if (c->pinned_tail) (void)hipHostFree(c->pinned_tail);
@@ -811,8 +816,49 @@ static int check_step(gat_ctx* c, const char* who) {
                                                    "the phase API with the exchange steps");
     return 0;
 }
+// Chunk-pipelined forward exchange of one layer (gat_comm_option GAT_COMM_PIPELINE = K > 1): the shard's rows are
+// projected in K row chunks on the compute stream; as soon as chunk k exists, its part of every rank's table slice is
+// exchanged on a second stream, while chunk k+1 is being projected.  The edge pass waits for the last part.  Chunk
+// boundaries are the same slice coordinates on every rank (multiples of 128 rows of max_rows), so the parts have fixed
+// counts.  Every PL / PR row is produced by the same fmaf chain as in one launch: results are bitwise those of the
+// unchunked exchange (tests/test_shard.py).  What can hide behind the exchange this way is the projection itself; the
+// edge pass needs the whole table.
+static int forward_exchange_pipelined(gat_ctx* c, int l) {
+    Layer& y = c->layers[l];
+    const int K = c->comm_chunks;
+    const int64_t max_rows = c->n_table / c->comm->world;
+    const int64_t rpc = ((max_rows + K - 1) / K + 127) / 128 * 128;       // rows per chunk, a multiple of the GEMM's row tile
+    if (!c->comm_stream) GAT_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    while ((int)c->comm_events.size() < K + 1) {
+        hipEvent_t e;
+        GAT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->comm_events.push_back(e);
+    }
+    const int64_t rowf = y.HD * st_bytes(c) / 4;                           // floats per PL row (bf16 rows: half)
+    char* own_rows = reinterpret_cast<char*>(y.PL) + c->table_row0 * y.HD * st_bytes(c);
+    Scope t(c, GAT_K_EXCHANGE);                                            // timed as a whole: projection chunks + their exchanges
+    for (int k = 0; k < K; ++k) {
+        const int64_t r0 = (int64_t)k * rpc, r1s = std::min<int64_t>(r0 + rpc, max_rows), r1 = std::min<int64_t>(r1s, c->n_rows);
+        if (r0 >= max_rows) break;
+        if (r1 > r0)
+            GAT_TRY(launch_project(Xin_of(c, l) + r0 * y.F, W_of(c, l), reinterpret_cast<float*>(own_rows + r0 * y.HD * st_bytes(c)),
+                                   y.PR + r0 * y.HD, r1 - r0, y.F, y.HD, kPartBoth, bf16(c), nullptr, c->stream));
+        GAT_HIP(hipEventRecord(c->comm_events[k], c->stream));
+        GAT_HIP(hipStreamWaitEvent(c->comm_stream, c->comm_events[k], 0));
+        GAT_TRY(c->comm->all_gather_part(y.PL, pl_slice(c, y), r0 * rowf, (r1s - r0) * rowf, c->comm_stream));
+    }
+    GAT_HIP(hipEventRecord(c->comm_events[K], c->comm_stream));
+    GAT_HIP(hipStreamWaitEvent(c->stream, c->comm_events[K], 0));
+    return 0;
+}
 static int forward_phases(gat_ctx* c) {
     for (int l = 0; l < c->cfg.num_layers; ++l) {
+        if (c->comm && needs_exchange(c, l) && c->comm_chunks > 1) {
+            GAT_TRY(check_layer(c, l));
+            GAT_TRY(forward_exchange_pipelined(c, l));
+            GAT_TRY(gat_layer_forward_edges(c, l));
+            continue;
+        }
         GAT_TRY(gat_layer_project(c, l));
         if (c->comm && needs_exchange(c, l)) {
             Scope t(c, GAT_K_EXCHANGE);
@@ -1013,6 +1059,11 @@ int gat_comm_init_host(gat_ctx* c, int32_t world, int32_t rank, const char* shm_
 int gat_comm_option(gat_ctx* c, int32_t option, int32_t value) {
     if (!c) return fail(GAT_E_INVALID, "null context");
     if (option == GAT_COMM_GPL_BF16) { c->comm_gpl_bf16 = value != 0; return 0; }
+    if (option == GAT_COMM_PIPELINE) {
+        if (value < 1 || value > 64) return fail(GAT_E_INVALID, "gat_comm_option: GAT_COMM_PIPELINE takes 1..64 chunks");
+        c->comm_chunks = value;
+        return 0;
+    }
     return fail(GAT_E_INVALID, "gat_comm_option: unknown option");
 }
 int gat_zero_grad(gat_ctx* c) {

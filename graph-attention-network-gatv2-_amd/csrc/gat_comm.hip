@@ -132,6 +132,18 @@ struct RcclComm final : Comm {
         GAT_NCCL(api, api->AllGather(table + (int64_t)rank * slice, table, (size_t)slice, kNcclFloat32, comm, s));
         return 0;
     }
+    // part of every slice: one send + one receive per peer, grouped (the direct exchange over the xGMI mesh); in place
+    int all_gather_part(float* table, int64_t slice, int64_t off, int64_t cnt, hipStream_t s) override {
+        if (cnt <= 0 || world == 1) return 0;
+        GAT_NCCL(api, api->GroupStart());
+        for (int q = 0; q < world; ++q) {
+            if (q == rank) continue;
+            GAT_NCCL(api, api->Send(table + (int64_t)rank * slice + off, (size_t)cnt, kNcclFloat32, q, comm, s));
+            GAT_NCCL(api, api->Recv(table + (int64_t)q * slice + off, (size_t)cnt, kNcclFloat32, q, comm, s));
+        }
+        GAT_NCCL(api, api->GroupEnd());
+        return 0;
+    }
     int reduce_scatter(float* table, int64_t slice, hipStream_t s) override {
         // in place: recvbuff == sendbuff + rank * recvcount
         GAT_NCCL(api, api->ReduceScatter(table, table + (int64_t)rank * slice, (size_t)slice, kNcclFloat32, kNcclSum, comm, s));
@@ -239,6 +251,18 @@ struct HostComm final : Comm {
         for (int p = 0; p < world; ++p)
             if (p != rank)
                 GAT_HIP(hipMemcpyAsync(table + (int64_t)p * slice, area(p), slice * sizeof(float), hipMemcpyHostToDevice, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        return meet();
+    }
+    int all_gather_part(float* table, int64_t slice, int64_t off, int64_t cnt, hipStream_t s) override {
+        if (cnt <= 0) return 0;
+        GAT_TRY(fits(slice));
+        GAT_HIP(hipMemcpyAsync(area(rank) + off, table + (int64_t)rank * slice + off, cnt * sizeof(float), hipMemcpyDeviceToHost, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        GAT_TRY(meet());
+        for (int p = 0; p < world; ++p)
+            if (p != rank)
+                GAT_HIP(hipMemcpyAsync(table + (int64_t)p * slice + off, area(p) + off, cnt * sizeof(float), hipMemcpyHostToDevice, s));
         GAT_HIP(hipStreamSynchronize(s));
         return meet();
     }

@@ -159,6 +159,8 @@ struct Comm {
     virtual ~Comm();
     // table: [world][slice] floats; the rank's slice already written / afterwards holding the sum
     virtual int all_gather(float* table, int64_t slice, hipStream_t s) = 0;
+    // the same for floats [off, off+cnt) of EVERY rank's slice only (chunk-pipelined forward exchange)
+    virtual int all_gather_part(float* table, int64_t slice, int64_t off, int64_t cnt, hipStream_t s) = 0;
     virtual int reduce_scatter(float* table, int64_t slice, hipStream_t s) = 0;
     // The same exchange with the REMOTE partial sums travelling as bf16 (half the xGMI volume): every rank rounds the
     // slices it sends to bf16 (nearest even), keeps its own partial in fp32, and adds what arrives in fp32 in ascending

@@ -170,8 +170,10 @@ int gat_comm_init_host(gat_ctx* ctx, int32_t world, int32_t rank, const char* sh
  *   GAT_COMM_GPL_BF16 = 1: in the gPL reduce-scatter the REMOTE partial sums travel as bf16 (half the xGMI volume of the
  *   backward exchange); each rank keeps its own partial in fp32 and adds the arrivals in fp32, in ascending rank order.
  *   Default 0 (fp32 on the wire).  Gradients then differ from the fp32 exchange by ~2^-9 relative per remote term: the
- *   parity bar of this mode is 1e-2 (like bf16 storage). */
-enum { GAT_COMM_GPL_BF16 = 1 };
+ *   parity bar of this mode is 1e-2 (like bf16 storage).
+ *   GAT_COMM_PIPELINE = K (1..64, default 1): the forward exchange of a layer runs in K row chunks on a second stream,
+ *   chunk k travelling while chunk k+1 is projected; results are bitwise those of K = 1. */
+enum { GAT_COMM_GPL_BF16 = 1, GAT_COMM_PIPELINE = 2 };
 int gat_comm_option(gat_ctx* ctx, int32_t option, int32_t value);
 /* forward + backward without a host round-trip in between; with a transport the loss and #correct
  * ride in the tail of the gradient all-reduce.  Returns the global loss sum / #correct. */

@@ -374,6 +374,12 @@ def test_library_transport_rccl_world1(pkg, orc):
     loss_b, correct_b = ctx.step()
     assert (loss_b, correct_b) == (loss, correct)
     assert np.array_equal(np.concatenate([ctx.grads_get(g) for g in range(3)]), grads)
+    # the chunk-pipelined forward exchange (second stream, events, chunked projections): bitwise the plain one
+    ctx.comm_option(pkg.abi.COMM_GPL_BF16, 0); ctx.comm_option(pkg.abi.COMM_PIPELINE, 3)
+    ctx.zero_grad()
+    loss_p, correct_p = ctx.step()
+    assert (loss_p, correct_p) == (loss, correct)
+    assert np.array_equal(np.concatenate([ctx.grads_get(g) for g in range(3)]), grads)
     ctx.close()
     assert launches == 2 + 2 + 1             # all-gather and reduce-scatter per layer, one all-reduce
     assert abs(loss - ref.loss_sum_f64) < 1e-4 * P["n"] and correct == ref.n_correct
@@ -475,3 +481,48 @@ def test_bf16_gpl_reduce_scatter_option(pkg):
         parity.check_rel("bf16 gPL exchange vs fp32 exchange", o["g1"], o["g0"], 1e-2)
         assert not np.array_equal(o["g1"], o["g0"])
         assert np.array_equal(o["g1"], outs[0]["g1"])
+
+
+def _pipeline_worker(rank, world, outdir, shm):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as entry
+    pkg = entry.load_package(); orc = entry.load_oracle()
+    P = _problem(n=700, e=6000)                     # max_rows > 128: several row chunks really exist
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    W, a, Wo = orc.xavier_params(cfg, 11)
+    S = pkg.shard
+    plan = S.make_plan(P["rp"], world, rank)
+    rp_l, ci_l = S.local_csr(plan, P["rp"], P["ci"])
+    lo, hi = plan.row0, plan.row0 + plan.n_rows
+    out = {}
+    for chunks in (1, 2, 5):
+        ctx = pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"], device=0)
+        ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
+        ctx.set_features(P["x"][lo:hi])                 # layer 0 exchanged too
+        ctx.set_labels(P["lab"][lo:hi])
+        for g, arr in enumerate((W, a, Wo)):
+            ctx.params_set(g, arr)
+        ctx.comm_init_host(world, rank, f"{shm}_{chunks}", 4 * max(plan.n_table * 64, ctx.n_params + 3))
+        ctx.comm_option(pkg.abi.COMM_PIPELINE, chunks)
+        ctx.zero_grad()
+        loss, correct = ctx.step()
+        out[f"g{chunks}"] = np.concatenate([ctx.grads_get(g) for g in range(3)]); out[f"l{chunks}"] = loss
+        out[f"pl{chunks}"] = ctx.tap(pkg.abi.TAP_PL, 1)
+        ctx.close()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), **out)
+
+
+@pytest.mark.gpu
+def test_chunk_pipelined_forward_exchange_is_bitwise_the_plain_one(pkg):
+    """GAT_COMM_PIPELINE = K: projection in K row chunks on the compute stream, each chunk's part of every table slice
+    exchanged on a second stream.  Same PL table, same loss, same gradients, bit for bit, for K = 2 and 5 vs 1."""
+    import torch.multiprocessing as mp
+    world = 3
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_pipeline_worker, args=(world, d, f"/gatv2_pipe_{os.getpid()}"), nprocs=world, join=True)
+        outs = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
+    for o in outs:
+        for k in (2, 5):
+            assert float(o[f"l{k}"]) == float(o["l1"])
+            assert np.array_equal(o[f"pl{k}"], o["pl1"])
+            assert np.array_equal(o[f"g{k}"], o["g1"])
