@@ -98,8 +98,8 @@ def cpu_baseline(pkg, workload, heads, outdims, sample_scale):
         per_edge = max(t / ds["e"], 1e-9)
         sample_scale = min(1.0, 30.0 / (per_edge * e_full))    # the 2k-edge probe over-estimates per-edge cost (threads idle)
     ds, t = run(sample_scale)
-    if t < 6.0 and sample_scale < 1.0:       # aim at 10-30 s of CPU work (contract): rescale once from the real rate (the
-        sample_scale = min(1.0, sample_scale * 8.0 / max(t, 1e-3))      # O(sum deg^2) term grows faster than the edge count)
+    if t < 8.0 and sample_scale < 1.0:       # aim at 10-30 s of CPU work (contract): rescale once from the measured rate
+        sample_scale = min(1.0, sample_scale * 14.0 / max(t, 1e-3))
         ds, t = run(sample_scale)
     return {
         "value": ds["e"] / t, "unit": "edges/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
