@@ -2,8 +2,10 @@
 //
 // The reference scatters per-edge gradient contributions with float atomicAdd (E:868-869 into
 // gx[src], E:772-786 into grad_W).  On gfx950 float atomics run at ≈1.3 TB/s chip-wide against
-// ≈6 TB/s for plain stores, so the backward instead STORES every edge's message row once into its
-// slot of a source-sorted scratch array and a second pass sums each source's contiguous slots
+// ≈6 TB/s for plain stores, so the backward instead STORES per edge, into its slot of a source-sorted
+// scratch array, either a 64-byte record (alpha, ge, LeakyReLU' decisions: the training path) or the
+// whole message row, and a second pass walks each source's contiguous slots: gpl_pull_* rebuilds the
+// messages from the records and one gathered row of g[dst] while it sums, gpl_sum_* just sums rows
 // (cdna_hip_programming.md Appendix B "Scatter / gather": store pass + per-destination sum pass).
 //   pos[e]      = slot of CSR edge e in (src, e)-sorted order   (stable radix sort: fixed order
 //                 inside every source's list => bitwise reproducible sums)

@@ -8,16 +8,21 @@
 //   a1 CSR->COO E:67-84
 // with ONE destination-segmented pass per direction over projected features
 //   PL = X·W_left^T, PR = X·W_right^T   (s[e,h,k] = PL[src,h,k] + PR[dst,h,k]).
-// A wave owns a work item = a CSR row, or a <=256-edge segment of a long row (power-law hubs
-// are split so that no wave runs longer than ~8 chunks).  Every neighbour row PL[src] is one
-// coalesced H*D-float read, the per-head reductions are DPP/shuffle all-reduces, the softmax is
-// online (single gather of PL[src] per edge), h_pre is written once without atomics, and the
-// softmax backward uses   sum_k galpha_k alpha_k == <g[dst,h,:], h_pre[dst,h,:]>
-// which makes it O(E) and single-pass.  Split rows are finished by small fix-up kernels that
-// merge the per-segment partials.
+// A work item = a CSR row, or a segment of a long row (power-law hubs are split: 256 edges, 64 on
+// graphs below 16 M edges).  Training path (edge_fwd3 / edge_bwd3): a LANE GROUP (H*D/N lanes, N = 4
+// channels per lane) owns an item, a wave carries 64/(H*D/N) items of similar length side by side;
+// parity-tap path and shapes without that layout: a wave owns an item and walks it in 16-edge chunks.
+// Every neighbour row PL[src] is one coalesced H*D-float read, the per-head reductions are
+// DPP/shuffle all-reduces, the softmax is online (single gather of PL[src] per edge), h_pre is
+// written once without atomics, and the softmax backward uses
+//   sum_k galpha_k alpha_k == <g[dst,h,:], h_pre[dst,h,:]>
+// which makes it O(E) and single-pass.  The backward leaves ONE 64-byte record per edge (alpha, ge and
+// the LeakyReLU' decisions) in its source-major slot; gat_csc.hip's pull pass turns the records into
+// gPL.  Split rows are finished by small fix-up kernels that merge the per-segment partials.
 //
-// HBM layouts: PL/PR/h_pre/g [rows][H*D] f32; alpha, ge [E][H] f32 (edge-major: the H values
-// of an edge are one 4H-byte segment); CSR int32; work items int4 {row, beg, end, slot|-1}.
+// HBM layouts: PL/PR/h_pre/g [rows][H*D] f32; alpha, ge [E][H] f32 (edge-major, taps only); records
+// [E+1][H*D/N] words by slot; CSR int32; work items int4 {row, beg, end, slot|-1}, longest first
+// inside windows of 4,096 rows.
 #include "gat_internal.h"
 
 #include <map>
