@@ -561,7 +561,9 @@ int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
                     int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, hipStream_t s) {
     if (n_table <= 0) return 0;
-    static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
+    // one wave per block for the pull kernel (GAT_GPL_WAVES=1|2|4): 5.03 / 5.11 / 5.30 ms per step on the Products shape — a
+    // 4-wave block lives as long as its longest list; the message-row sum (launch_gpl_sum) measured the other way round
+    static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
     const int HD = H * D;
     const bool last = gh != nullptr && hbits != nullptr;
 #define PULL_ARGS(G_) src_ptr, stash, cdst, G_, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, items, n_items, s
