@@ -105,8 +105,9 @@ class Flips:
         return {"s_params": self.n_s_params, "s_gx": self.n_s_gx, "h_pre": self.n_h}
 
 
-def find_flips(orc, cfg, row_ptr, col_idx, x, W, ref, ctx, A):
-    """ctx: a GatContext created with keep_taps=True after forward+backward; ref: orc.step() of the same inputs."""
+def find_flips(orc, cfg, row_ptr, col_idx, x, W, ref, ctx, A, cache=None):
+    """ctx: a GatContext after forward+backward (PL / PR / h_pre taps need no keep_taps); ref: orc.step() of the same
+    inputs; cache: dict shared by the comparisons of several contexts on the same inputs (the oracle's side is reused)."""
     src = np.asarray(col_idx, np.int64)
     dst = np.asarray(ref.dst, np.int64)
     gpu_s, gpu_h = [], []
@@ -116,12 +117,15 @@ def find_flips(orc, cfg, row_ptr, col_idx, x, W, ref, ctx, A):
         s = (PL[src] + PR[dst]).astype(np.float32)                       # the kernels' own fp32 add (v + pr)
         gpu_s.append((s > 0).reshape(len(src), H, D))
         gpu_h.append(ctx.tap(A.TAP_HPRE, l) > 0)
-    orc_lr, orc_il = orc.presum_signs(cfg, row_ptr, col_idx, x, W, ref)
+    cache = {} if cache is None else cache
+    if "orc_signs" not in cache:
+        cache["orc_signs"] = orc.presum_signs(cfg, row_ptr, col_idx, x, W, ref)
+    orc_lr, orc_il = cache["orc_signs"]
     orc_h = [ref.taps["hpre"][l] > 0 for l in range(cfg.L)]
     return Flips(cfg, gpu_s, gpu_h, orc_lr, orc_il, orc_h)
 
 
-def expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, max_flips=MAX_FLIPS):
+def expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, max_flips=MAX_FLIPS, cache=None):
     """-> dict(g, galpha, ge, gx (lists per layer, reference layouts), gradW, grada, gradWo): the oracle's values,
     plus — only where sign decisions differ — the fp64-evaluated effect of the HIP path's decisions."""
     exp = dict(g=[t for t in ref.taps["g"]], galpha=list(ref.taps["galpha"]), ge=list(ref.taps["ge"]),
@@ -131,9 +135,12 @@ def expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, m
     if flips.total == 0:
         return exp
     import ref64
-    fw = ref64.forward(cfg, row_ptr, col_idx, labels, x, W, a, Wo)
+    cache = {} if cache is None else cache          # the fp64 forward and the oracle-side backward do not depend on the HIP context
+    if "fw" not in cache:
+        cache["fw"] = ref64.forward(cfg, row_ptr, col_idx, labels, x, W, a, Wo)
+        cache["b_orc"] = ref64.backward(cfg, cache["fw"], flips.orc_lr, flips.orc_il, flips.orc_h)
+    fw, b_orc = cache["fw"], cache["b_orc"]
     b_gpu = ref64.backward(cfg, fw, flips.gpu_s, flips.gpu_s, flips.gpu_h)
-    b_orc = ref64.backward(cfg, fw, flips.orc_lr, flips.orc_il, flips.orc_h)
     out = {}
     for k in ("gradW", "grada", "gradWo"):
         out[k] = np.asarray(exp[k], np.float64) + (b_gpu[k] - b_orc[k])
@@ -144,12 +151,12 @@ def expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, m
 
 
 def check_context_gradients(orc, A, cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, ctx, taps=False, prefix="",
-                            max_flips=MAX_FLIPS, floor=1e-12):
+                            max_flips=MAX_FLIPS, floor=1e-12, cache=None):
     """The whole gradient comparison of one context after forward+backward against the oracle result `ref`, at
     GTOL with the kink bookkeeping above.  taps=True also compares g, galpha, ge and gx per layer (needs a
     context created with keep_taps=True).  -> Flips"""
-    flips = find_flips(orc, cfg, row_ptr, col_idx, x, W, ref, ctx, A)
-    exp = expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, max_flips)
+    flips = find_flips(orc, cfg, row_ptr, col_idx, x, W, ref, ctx, A, cache)
+    exp = expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, max_flips, cache)
     if taps:
         for l in range(cfg.L - 1, -1, -1):
             check_rel(f"{prefix}g[{l}]", ctx.tap(A.TAP_G, l), exp["g"][l])

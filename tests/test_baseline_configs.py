@@ -33,6 +33,7 @@ def _literal_full_check(pkg, orc, name, heads, outdims, mt):
     W, a, Wo = orc.xavier_params(cfg, 42)
     rp, ci, lab, x = ds["row_ptr"], ds["col_idx"], ds["labels"], ds["x"]
     ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo, mt_baseline=mt)
+    cache = {}                                      # oracle-side sign decisions / fp64 forward: shared by the two contexts below
     with pkg.GatContext(cfg.heads, cfg.outdims, ds["f"], ds["c"], keep_taps=True) as ctx:
         ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
         ctx.params_set(A.PARAM_W, W); ctx.params_set(A.PARAM_A, a); ctx.params_set(A.PARAM_WO, Wo)
@@ -51,7 +52,7 @@ def _literal_full_check(pkg, orc, name, heads, outdims, mt):
         assert correct == ref.n_correct
         entries = sum(len(ci) * h * d for h, d in zip(heads, outdims))
         parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx, taps=True,
-                                       max_flips=max(parity.MAX_FLIPS, int(2e-6 * entries)))
+                                       max_flips=max(parity.MAX_FLIPS, int(2e-6 * entries)), cache=cache)
     # the training path (no taps, packed kernels, fused head) on the same inputs: loss and parameter gradients
     with pkg.GatContext(cfg.heads, cfg.outdims, ds["f"], ds["c"]) as ctx:
         ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
@@ -61,7 +62,7 @@ def _literal_full_check(pkg, orc, name, heads, outdims, mt):
         check_abs("train path loss/N", loss / n, ref.loss_sum_f64 / n)
         assert correct == ref.n_correct
         parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx, prefix="train path ",
-                                       max_flips=max(parity.MAX_FLIPS, int(2e-6 * entries)))
+                                       max_flips=max(parity.MAX_FLIPS, int(2e-6 * entries)), cache=cache)
 
 
 def test_config1_cora_shape_full(pkg, orc):
