@@ -107,8 +107,8 @@ constexpr int kKC = 128;          // K chunk resident in LDS
 
 }  // namespace
 
-// blocks of a 256-thread kernel resident on the whole chip (occupancy API incl. dynamic LDS), cached
-int64_t resident_blocks(const void* fn, size_t dyn_lds) {
+// blocks of a kernel (256 threads unless said otherwise) resident on the whole chip (occupancy API incl. dynamic LDS), cached
+int64_t resident_blocks(const void* fn, size_t dyn_lds, int threads) {
     static std::mutex mu;
     static std::map<std::pair<const void*, size_t>, int64_t> cache;
     std::lock_guard<std::mutex> lock(mu);
@@ -116,7 +116,7 @@ int64_t resident_blocks(const void* fn, size_t dyn_lds) {
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     int per_cu = 0, dev = 0, cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -315,6 +315,162 @@ __global__ __launch_bounds__(256) void rowgemm_pipe_kernel(AS as, BS bs, EP ep, 
     }
 }
 
+// ---- the same product on the bf16 matrix pipe, fp32 operands cut into three bf16 pieces -----------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate, and at Products size every dense kernel of the step is bound
+// by it, not by HBM.  An fp32 value is EXACTLY hi + mid + lo with three bf16 pieces of 8 significant bits
+// each (cut by truncation: the remainders x - hi and (x - hi) - mid are exact in fp32), a bf16 x bf16 product is exact
+// in fp32, and the MFMA accumulates in fp32.  Of the nine piece products of a·b the six with (piece index of a) +
+// (piece index of b) <= 2 are kept: the dropped ones sum to < 2^-23 |a·b|, the size of the rounding of one fp32
+// product.  Six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles for K = 16) replace eight 32x32x2_f32 (8 x 64 cycles), and
+// the kernel becomes HBM-bound.  Small terms are accumulated first.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// two floats -> the packed (x0 | x1 << 16) bf16 pairs of their hi / mid / lo pieces
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                 // {u1[31:16], u0[31:16]}
+    const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+    const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(v0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+struct Pieces { uint4 hi, mid, lo; };                                // 8 consecutive k of one row / column
+__device__ __forceinline__ Pieces split8(const float4& a, const float4& b) {
+    Pieces p;
+    split_pair(a.x, a.y, p.hi.x, p.mid.x, p.lo.x);
+    split_pair(a.z, a.w, p.hi.y, p.mid.y, p.lo.y);
+    split_pair(b.x, b.y, p.hi.z, p.mid.z, p.lo.z);
+    split_pair(b.z, b.w, p.hi.w, p.mid.w, p.lo.w);
+    return p;
+}
+__device__ __forceinline__ v16f mfma_bf16(const uint4& a, const uint4& b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// C[M][N] = A[M][K] · B[K][N] for K <= 128.  WAVES waves, each owning 32 rows x (NT*32) columns of a (WAVES*32)-row
+// tile; blocks persistent over row tiles.  B lives in LDS for the lifetime of the block, already cut into pieces and
+// in fragment order: plane p (hi, mid, lo), k-step ks (16 k), half h, column n -> the 8 bf16 of k = 16 ks + 8 h .. + 7
+// (lane (n, h) of the 32x32x16 B operand reads 16 contiguous bytes, lanes of a half 16 B apart: conflict-free
+// ds_read_b128).  A streams from HBM straight into the operand layout (lane (row, h) holds k = 8h .. 8h+7: two float4)
+// through a ring of kRing k-steps per wave, kRing-1 of them in flight across tile boundaries.
+template <int NT, int WAVES, bool VEC4, class AS, class BS, class EP, int kRing = 4>
+__global__ __launch_bounds__(WAVES * 64) void rowgemm_x3_kernel(AS as, BS bs, EP ep, int64_t M, int32_t N, int32_t K) {
+    constexpr int NW = NT * 32, TR = WAVES * 32;
+    extern __shared__ uint4 Bq[];                     // [3][KS][2][NW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.y * NW;
+    const int KS = (K + 15) >> 4;
+    const int plane = KS * 2 * NW;
+    for (int idx = threadIdx.x; idx < KS * 2 * NW; idx += WAVES * 64) {
+        int n, kh;
+        if constexpr (BS::kAlongK) { kh = idx % (KS * 2); n = idx / (KS * 2); }
+        else { n = idx % NW; kh = idx / NW; }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kh * 8 + j;
+            v[j] = (k < K && n0 + n < N) ? bs.at(k, n0 + n) : 0.f;
+        }
+        const Pieces p = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+        Bq[kh * NW + n] = p.hi; Bq[plane + kh * NW + n] = p.mid; Bq[2 * plane + kh * NW + n] = p.lo;
+    }
+    __syncthreads();
+    const int64_t ntiles = (M + TR - 1) / TR;
+    if ((int64_t)blockIdx.x >= ntiles) return;
+    const int64_t my_tiles = (ntiles - 1 - blockIdx.x) / gridDim.x + 1;
+    const int64_t total = my_tiles * KS;              // k-steps this wave walks
+
+    auto load_a = [&](int64_t tile, int step, float4 (&buf)[2]) {
+        int64_t row = tile * TR + wave * 32 + li;
+        row = row < M ? row : M - 1;                  // rows past the end: a valid address, results never stored
+        const int kk = step * 16 + 8 * half;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            buf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (VEC4) {
+                if (kk + 4 * q < K) buf[q] = as.load4(row, kk + 4 * q);
+            } else {
+                if (kk + 4 * q + 0 < K) buf[q].x = as.load1(row, kk + 4 * q + 0);
+                if (kk + 4 * q + 1 < K) buf[q].y = as.load1(row, kk + 4 * q + 1);
+                if (kk + 4 * q + 2 < K) buf[q].z = as.load1(row, kk + 4 * q + 2);
+                if (kk + 4 * q + 3 < K) buf[q].w = as.load1(row, kk + 4 * q + 3);
+            }
+        }
+    };
+    v16f acc[NT];
+    auto clear = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    };
+    auto mma = [&](int step, const float4 (&buf)[2]) {
+        const Pieces a = split8(buf[0], buf[1]);
+        const uint4* bp = Bq + (step * 2 + half) * NW + li;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const uint4 bh = bp[nt * 32], bm = bp[plane + nt * 32], bl = bp[2 * plane + nt * 32];
+            acc[nt] = mfma_bf16(a.lo, bh, acc[nt]);
+            acc[nt] = mfma_bf16(a.hi, bl, acc[nt]);
+            acc[nt] = mfma_bf16(a.mid, bm, acc[nt]);
+            acc[nt] = mfma_bf16(a.mid, bh, acc[nt]);
+            acc[nt] = mfma_bf16(a.hi, bm, acc[nt]);
+            acc[nt] = mfma_bf16(a.hi, bh, acc[nt]);
+        }
+    };
+    auto store = [&](int64_t tile) {                  // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        float hv[EP::kTwoPhase ? NT : 1][16];
+        if constexpr (EP::kTwoPhase) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t orow = tile * TR + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int col = n0 + nt * 32 + li;
+                    hv[nt][r] = (orow < M && col < N) ? ep.pre(orow, col) : 0.f;
+                }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t orow = tile * TR + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int col = n0 + nt * 32 + li;
+                if (orow < M && col < N) {
+                    if constexpr (EP::kTwoPhase) ep.apply(orow, col, acc[nt][r], hv[nt][r]);
+                    else ep(orow, col, acc[nt][r]);
+                }
+            }
+    };
+    // two cursors over the wave's (tile, step) sequence: the loader runs kRing-1 steps ahead of the multiplier
+    int64_t lt = blockIdx.x, ct = blockIdx.x;
+    int ls = 0, cs = 0;
+    float4 ring[kRing][2];
+    clear();
+#pragma unroll
+    for (int r = 0; r < kRing - 1; ++r) {
+        if (r < total) {
+            load_a(lt, ls, ring[r]);
+            if (++ls == KS) { ls = 0; lt += gridDim.x; }
+        }
+    }
+    for (int64_t q = 0; q < total; q += kRing) {
+#pragma unroll
+        for (int r = 0; r < kRing; ++r) {
+            if (q + r + kRing - 1 < total) {
+                load_a(lt, ls, ring[(r + kRing - 1) % kRing]);
+                if (++ls == KS) { ls = 0; lt += gridDim.x; }
+            }
+            if (q + r < total) {
+                mma(cs, ring[r]);
+                if (++cs == KS) { store(ct); clear(); cs = 0; ct += gridDim.x; }
+            }
+        }
+    }
+}
+
 // ---- projection of FEW rows with a LONG K (Cora-shape: 2,708 x 1,433; Pubmed-shape: 19,717 x 500) ----------------
 // The row-streaming kernel above gives such a product 22 (Cora) or 154 (Pubmed) row tiles for 256 CUs, each walking
 // K in 128-wide chunks one after the other.  Here a block owns 128 rows x 128 columns x ONE 128-wide K chunk (grid.z =
@@ -400,6 +556,31 @@ int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, 
     const int NW = NT * 32;
     const int kc_lds = ((K < kKC ? K : kKC) + 7) & ~7;
     const size_t lds = (size_t)kc_lds * NW * sizeof(float);
+    static const int x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return e ? atoi(e) : 8; }();   // A/B: 0 = fp32 MFMA; 4 / 8 = waves per block
+    if (x3 != 0 && K <= 128) {
+        const int KS = (K + 15) / 16;
+        const size_t lds3 = (size_t)3 * KS * 2 * NW * sizeof(uint4);
+#define GAT_ROWGEMM_X3(NT_, W_, V_)                                                                           \
+    {                                                                                                         \
+        auto kern = rowgemm_x3_kernel<NT_, W_, V_, AS, BS, EP>;                                               \
+        static const int attr_set = [&] {                                                                     \
+            return (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        }();                                                                                                  \
+        (void)attr_set;                                                                                       \
+        const int64_t nt_ = (M + W_ * 32 - 1) / (W_ * 32);                                                    \
+        int64_t res = resident_blocks((const void*)kern, lds3, W_ * 64);                                    \
+        const dim3 grid((unsigned)(nt_ < res ? nt_ : res), (unsigned)((N + NW - 1) / NW));                    \
+        hipLaunchKernelGGL(kern, grid, dim3(W_ * 64), lds3, s, as, bs, ep, M, N, K);                           \
+    }
+#define GAT_ROWGEMM_X3_NT(W_, V_)                                                                             \
+    { if (NT == 4) GAT_ROWGEMM_X3(4, W_, V_) else if (NT == 2) GAT_ROWGEMM_X3(2, W_, V_) else GAT_ROWGEMM_X3(1, W_, V_) }
+        if (x3 == 4) { if (vec4) GAT_ROWGEMM_X3_NT(4, true) else GAT_ROWGEMM_X3_NT(4, false) }
+        else { if (vec4) GAT_ROWGEMM_X3_NT(8, true) else GAT_ROWGEMM_X3_NT(8, false) }
+#undef GAT_ROWGEMM_X3_NT
+#undef GAT_ROWGEMM_X3
+        GAT_HIP(hipGetLastError());
+        return 0;
+    }
     const int64_t ntiles = (M + 127) / 128;
     if constexpr (!EP::kTwoPhase) {
         static const bool pipe = [] { const char* e = getenv("GAT_GEMM_PIPE"); return !(e && e[0] == '0'); }();   // A/B
@@ -557,15 +738,207 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
             }
 }
 
+// ---- grad_w on the bf16 pipe (three-piece operands, as rowgemm_x3_kernel) ---------------------------------------------
+// Both operands are k-strided in memory (k = node is the row index of [gPL|gPR] and of X), and the 32x32x16 operand wants
+// 8 consecutive k per lane: node tiles of 16 are cut into pieces on their way into LDS, kept there in memory orientation
+// ([node][channel] bf16, one image per piece) and read back transposed by ds_read_b64_tr_b16 (a 16-lane group reads 4
+// rows x 16 columns, each lane receiving one column).  Image layout: 8-row x 32-column subtiles of 512 B, the four 16-B
+// chunks of a subtile row XORed with (row>>2)&3 (conflict-free for the 8-B piece writes and the transposed reads).
+// Global loads run kDepth node tiles ahead in registers; one __syncthreads per 16 nodes.
+template <int COLS>
+__device__ __forceinline__ int img_off(int row, int col4) {                     // byte offset of columns col4*4 .. +3 of a row
+    const int ch = col4 >> 1;
+    return (COLS / 32) * 512 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3)) + 8 * (col4 & 1);
+}
+typedef short tr4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 tr_frag(const char* img, int off0, int off1) {  // rows 8h..8h+3 | 8h+4..8h+7 of one column
+    const tr4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(img + off0));
+    const tr4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr4*)(img + off1));
+    const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+    return make_uint4(ua.x, ua.y, ub.x, ub.y);
+}
+
+template <bool VEC4, int WM, int BN, int kDepth = 4>
+__global__ __launch_bounds__(256) void gradw_x3_kernel(const float* __restrict__ gPL, const float* __restrict__ gPR,
+                                                       const float* __restrict__ X, float* __restrict__ slabs,
+                                                       int64_t n_rows, int32_t HD, int32_t F, int64_t kchunk,
+                                                       int32_t c_base, int32_t M) {
+    constexpr int KT = 16, BM = 64 * WM;
+    constexpr int WN = 4 / WM, NY = BN / WN / 32;
+    static_assert(NY >= 1, "tile shape");
+    constexpr int A_IMG = KT * BM * 2, B_IMG = KT * BN * 2;          // bytes of one piece image
+    constexpr int STAGE = 3 * (A_IMG + B_IMG);
+    constexpr int NA = KT * BM / 4 / 256, NB = KT * BN / 4 / 256;    // float4 per thread per tile
+    static_assert(NA >= 1 && NB >= 1, "staging shape");
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, half = lane >> 5;
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const int64_t kb = (int64_t)blockIdx.z * kchunk;
+    const int64_t ke = (kb + kchunk < n_rows) ? kb + kchunk : n_rows;
+    v16f acc[2][NY];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NY; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    struct Raw { float4 a[NA], b[NB]; };
+    auto load_tile = [&](int64_t n0, Raw& t) {
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int idx = tid + 256 * p;
+            const int kk = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
+            const int64_t node = n0 + kk;
+            t.a[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ci = c_base + i0 + c;
+            if (node < ke && i0 + c < M) {
+                if constexpr (VEC4) {
+                    t.a[p] = ci < HD ? *reinterpret_cast<const float4*>(gPL + node * HD + ci)
+                                     : *reinterpret_cast<const float4*>(gPR + node * HD + (ci - HD));
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cc = ci + q;
+                        v[q] = (cc - c_base) < M ? (cc < HD ? gPL[node * HD + cc] : gPR[node * HD + (cc - HD)]) : 0.f;
+                    }
+                    t.a[p] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int idx = tid + 256 * p;
+            const int kk = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+            const int64_t node = n0 + kk;
+            t.b[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int cj = j0 + c;
+            if (node < ke && cj < F) {
+                if constexpr (VEC4) {
+                    t.b[p] = *reinterpret_cast<const float4*>(X + node * F + cj);
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (cj + q < F) ? X[node * F + cj + q] : 0.f;
+                    t.b[p] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    };
+    auto put = [&](char* img, int img_bytes, int off, const float4& v) {
+        uint2 h, m, l;
+        split_pair(v.x, v.y, h.x, m.x, l.x);
+        split_pair(v.z, v.w, h.y, m.y, l.y);
+        *reinterpret_cast<uint2*>(img + off) = h;
+        *reinterpret_cast<uint2*>(img + img_bytes + off) = m;
+        *reinterpret_cast<uint2*>(img + 2 * img_bytes + off) = l;
+    };
+    auto store_tile = [&](int buf, const Raw& t) {
+        char* base = lds + buf * STAGE;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) {
+            const int idx = tid + 256 * p;
+            put(base, A_IMG, img_off<BM>(idx / (BM / 4), idx % (BM / 4)), t.a[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int idx = tid + 256 * p;
+            put(base + 3 * A_IMG, B_IMG, img_off<BN>(idx / (BN / 4), idx % (BN / 4)), t.b[p]);
+        }
+    };
+    // transposed-read addresses of this lane (Mechanism of ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies row q,
+    // columns 4p..4p+3 of the group's 4 x 16 block); group g = lane>>4 serves operand lanes (col 16(g&1) + i, half g>>1)
+    const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int trow = 8 * (g >> 1) + tq;               // + 4 for the second read
+    int offA[2][2], offB[NY][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            offA[x][j] = img_off<BM>(trow + 4 * j, (wm * 64 % BM + x * 32 + 16 * (g & 1)) / 4 + tp);
+#pragma unroll
+    for (int y = 0; y < NY; ++y)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            offB[y][j] = img_off<BN>(trow + 4 * j, (wn * (NY * 32) + y * 32 + 16 * (g & 1)) / 4 + tp);
+    auto mma_tile = [&](int buf) {
+        const char* base = lds + buf * STAGE;
+        uint4 a[2][3], b[NY][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int x = 0; x < 2; ++x) a[x][pl] = tr_frag(base + pl * A_IMG, offA[x][0], offA[x][1]);
+#pragma unroll
+            for (int y = 0; y < NY; ++y) b[y][pl] = tr_frag(base + 3 * A_IMG + pl * B_IMG, offB[y][0], offB[y][1]);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < NY; ++y) {
+                acc[x][y] = mfma_bf16(a[x][2], b[y][0], acc[x][y]);
+                acc[x][y] = mfma_bf16(a[x][0], b[y][2], acc[x][y]);
+                acc[x][y] = mfma_bf16(a[x][1], b[y][1], acc[x][y]);
+                acc[x][y] = mfma_bf16(a[x][1], b[y][0], acc[x][y]);
+                acc[x][y] = mfma_bf16(a[x][0], b[y][1], acc[x][y]);
+                acc[x][y] = mfma_bf16(a[x][0], b[y][0], acc[x][y]);
+            }
+    };
+
+    const int64_t ntile = (ke - kb + KT - 1) / KT;
+    Raw ring[kDepth];                                 // ring[t % kDepth] holds node tile t until it is cut into LDS
+    if (ntile > 0) {
+        load_tile(kb, ring[0]);
+        store_tile(0, ring[0]);
+#pragma unroll
+        for (int d = 1; d < kDepth; ++d) load_tile(kb + (int64_t)d * KT, ring[d]);      // past ke: zeros, no loads
+        load_tile(kb + (int64_t)kDepth * KT, ring[0]);
+    }
+    __syncthreads();
+    for (int64_t t0 = 0; t0 < ntile; t0 += kDepth) {
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) {
+            const int64_t t = t0 + d;
+            if (t < ntile) {
+                mma_tile((int)(t & 1));
+                if (t + 1 < ntile) {
+                    store_tile((int)((t + 1) & 1), ring[(d + 1) % kDepth]);
+                    load_tile(kb + (t + 1 + kDepth) * KT, ring[(d + 1) % kDepth]);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    float* out = slabs + (int64_t)blockIdx.z * M * F;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < NY; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int col = j0 + wn * (NY * 32) + y * 32 + li;
+                if (row < M && col < F) out[(int64_t)row * F + col] = acc[x][y][r];
+            }
+}
+
 inline int grad_w_bm(int32_t M) { return (M % 128 == 0 || M % 128 > 64) ? 128 : 64; }
 inline int grad_w_bn(int32_t M, int32_t F) { return (grad_w_bm(M) == 128 && F <= 64) ? 64 : 128; }   // 64 only in the 2x2-wave shape
 
+static bool grad_w_x3() {
+    static const bool on = [] { const char* e = getenv("GAT_GRADW_X3"); return !(e && e[0] == '0'); }();     // A/B: 0 = fp32 MFMA
+    return on;
+}
 int64_t grad_w_kchunk(int64_t n_rows, int32_t F, int32_t M) {
     const int bm = grad_w_bm(M), bn = grad_w_bn(M, F);
     const int64_t tiles = (((int64_t)M + bm - 1) / bm) * (((int64_t)F + bn - 1) / bn);
     // split-K over exactly the blocks that fit at once (LDS-limited: 64 / 48 KiB per block)
-    int64_t splits = resident_blocks(bm == 128 ? (bn == 64 ? (const void*)gradw_kernel<true, 2, 64> : (const void*)gradw_kernel<true, 2>)
-                                               : (const void*)gradw_kernel<true, 1>, 0) / tiles;
+    const void* fn = grad_w_x3() ? (bm == 128 ? (bn == 64 ? (const void*)gradw_x3_kernel<true, 2, 64> : (const void*)gradw_x3_kernel<true, 2, 128>)
+                                              : (const void*)gradw_x3_kernel<true, 1, 128>)
+                                 : (bm == 128 ? (bn == 64 ? (const void*)gradw_kernel<true, 2, 64> : (const void*)gradw_kernel<true, 2>)
+                                              : (const void*)gradw_kernel<true, 1>);
+    int64_t splits = resident_blocks(fn, 0) / tiles;
     if (splits < 1) splits = 1;
     int64_t kchunk = (n_rows + splits - 1) / splits;
     kchunk = ((kchunk + 31) / 32) * 32;
@@ -636,7 +1009,11 @@ int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float
     const int bm = grad_w_bm(M), bn = grad_w_bn(M, F);
     const dim3 grid((unsigned)((F + bn - 1) / bn), (unsigned)((M + bm - 1) / bm), (unsigned)ksplit);
     const bool vec4 = (F % 4 == 0) && (HD % 4 == 0) && aligned16(X) && aligned16(gPL_rows) && aligned16(gPR);
-#define GAT_GRADW(V_, WM_, BN_) hipLaunchKernelGGL((gradw_kernel<V_, WM_, BN_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M)
+#define GAT_GRADW(V_, WM_, BN_)                                                                                             \
+    do {                                                                                                                    \
+        if (grad_w_x3()) hipLaunchKernelGGL((gradw_x3_kernel<V_, WM_, BN_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M); \
+        else hipLaunchKernelGGL((gradw_kernel<V_, WM_, BN_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M); \
+    } while (0)
     if (vec4) { if (bm == 128 && bn == 64) GAT_GRADW(true, 2, 64); else if (bm == 128) GAT_GRADW(true, 2, 128); else GAT_GRADW(true, 1, 128); }
     else { if (bm == 128 && bn == 64) GAT_GRADW(false, 2, 64); else if (bm == 128) GAT_GRADW(false, 2, 128); else GAT_GRADW(false, 1, 128); }
 #undef GAT_GRADW

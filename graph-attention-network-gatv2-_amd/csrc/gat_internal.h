@@ -183,7 +183,7 @@ int launch_reduce_gradw(const float* slabs, int32_t ksplit, int32_t HD, int32_t 
 // Blocks of a 256-thread kernel that are resident on the whole chip at once (occupancy API incl.
 // dynamic LDS; cached).  Persistent kernels use exactly this grid: a larger one runs a second,
 // partly filled round of blocks.
-int64_t resident_blocks(const void* fn, size_t dyn_lds);
+int64_t resident_blocks(const void* fn, size_t dyn_lds, int threads = 256);
 
 // layout converters for taps / op-level entry points
 int launch_transpose_eh_to_he(const float* src_eh, float* dst_he, int64_t E, int32_t H, hipStream_t s);
