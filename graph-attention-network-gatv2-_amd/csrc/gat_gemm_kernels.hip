@@ -534,6 +534,77 @@ __global__ __launch_bounds__(256) void project_splitk_kernel(ASrcRows as, BSrcPr
             if (orow < M && col < N) out[orow * N + col] = acc[nt][r];
         }
 }
+// the same block shape on the bf16 pipe (three-piece operands: rowgemm_x3_kernel); B chunk = 3 piece planes in LDS (96 KiB)
+template <bool VEC4>
+__global__ __launch_bounds__(256) void project_splitk_x3_kernel(ASrcRows as, BSrcProject bs, float* __restrict__ slabs,
+                                                                int64_t M, int32_t N, int32_t K) {
+    constexpr int NW = 128, NT = 4, KC = 128, KS = KC / 16, plane = KS * 2 * NW;
+    extern __shared__ uint4 Bq[];                     // [3][KS][2][NW]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.y * NW;
+    const int k0 = blockIdx.z * KC;
+    const int kc = (K - k0 < KC) ? (K - k0) : KC;
+    int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + li;
+    row = row < M ? row : M - 1;
+    float4 af[KS][2];                                 // the wave's A fragments of the chunk: all in flight behind the B fill
+#pragma unroll
+    for (int st = 0; st < KS; ++st)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kk = st * 16 + 8 * half + 4 * q;
+            af[st][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (VEC4) {
+                if (kk < kc) af[st][q] = as.load4(row, k0 + kk);
+            } else {
+                if (kk + 0 < kc) af[st][q].x = as.load1(row, k0 + kk + 0);
+                if (kk + 1 < kc) af[st][q].y = as.load1(row, k0 + kk + 1);
+                if (kk + 2 < kc) af[st][q].z = as.load1(row, k0 + kk + 2);
+                if (kk + 3 < kc) af[st][q].w = as.load1(row, k0 + kk + 3);
+            }
+        }
+    for (int idx = threadIdx.x; idx < KS * 2 * NW; idx += 256) {   // consecutive threads -> consecutive k-octets of one column
+        const int kh = idx % (KS * 2), n = idx / (KS * 2);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = kh * 8 + j;
+            v[j] = (kk < kc && n0 + n < N) ? bs.at(k0 + kk, n0 + n) : 0.f;
+        }
+        const Pieces p = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+        Bq[kh * NW + n] = p.hi; Bq[plane + kh * NW + n] = p.mid; Bq[2 * plane + kh * NW + n] = p.lo;
+    }
+    __syncthreads();
+    v16f acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+        const Pieces a = split8(af[st][0], af[st][1]);
+        const uint4* bp = Bq + (st * 2 + half) * NW + li;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const uint4 bh = bp[nt * 32], bm = bp[plane + nt * 32], bl = bp[2 * plane + nt * 32];
+            acc[nt] = mfma_bf16(a.lo, bh, acc[nt]);
+            acc[nt] = mfma_bf16(a.hi, bl, acc[nt]);
+            acc[nt] = mfma_bf16(a.mid, bm, acc[nt]);
+            acc[nt] = mfma_bf16(a.mid, bh, acc[nt]);
+            acc[nt] = mfma_bf16(a.hi, bm, acc[nt]);
+            acc[nt] = mfma_bf16(a.hi, bh, acc[nt]);
+        }
+    }
+    float* out = slabs + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t orow = (int64_t)blockIdx.x * 128 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int col = n0 + nt * 32 + li;
+            if (orow < M && col < N) out[orow * N + col] = acc[nt][r];
+        }
+}
 template <class EP>
 __global__ __launch_bounds__(256) void project_reduce_kernel(const float* __restrict__ slabs, int32_t ksplit, int64_t M, int32_t N, EP ep) {
     const int64_t total = M * N, stride = (int64_t)gridDim.x * blockDim.x;
@@ -964,9 +1035,22 @@ int launch_project(const float* X, const float* W, float* PL_rows, float* PR, in
     if (scratch != nullptr && n_rows > 0 && project_wants_splitk(n_rows, N, F)) {
         const int ksplit = (F + 127) / 128;
         const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)ksplit);
-        const size_t lds = (size_t)(128 * 128) * sizeof(float);
-        if (vec4) hipLaunchKernelGGL(project_splitk_kernel<true>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
-        else hipLaunchKernelGGL(project_splitk_kernel<false>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+        static const bool x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return !(e && e[0] == '0'); }();       // A/B: 0 = fp32 MFMA
+        if (x3) {
+            const size_t lds = (size_t)3 * 8 * 2 * 128 * sizeof(uint4);
+            static const int attr_set = [] {
+                (void)hipFuncSetAttribute((const void*)project_splitk_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)project_splitk_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                return 0;
+            }();
+            (void)attr_set;
+            if (vec4) hipLaunchKernelGGL(project_splitk_x3_kernel<true>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+            else hipLaunchKernelGGL(project_splitk_x3_kernel<false>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+        } else {
+            const size_t lds = (size_t)(128 * 128) * sizeof(float);
+            if (vec4) hipLaunchKernelGGL(project_splitk_kernel<true>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+            else hipLaunchKernelGGL(project_splitk_kernel<false>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+        }
         const int64_t rb = std::min<int64_t>((n_rows * N + 255) / 256, 4096);
         if (pl_bf16) hipLaunchKernelGGL(project_reduce_kernel<EpiProject<true>>, dim3((unsigned)rb), dim3(256), 0, s, scratch, ksplit, n_rows, N, EpiProject<true>{PL_rows, PR, HD, j0});
         else hipLaunchKernelGGL(project_reduce_kernel<EpiProject<false>>, dim3((unsigned)rb), dim3(256), 0, s, scratch, ksplit, n_rows, N, EpiProject<false>{PL_rows, PR, HD, j0});
