@@ -44,7 +44,9 @@ void build_worklist(const int32_t* rp, int64_t n_rows, WorkList& w) {
     // GAT_SEG_EDGES=<n>: sweep of the hub-row segment length.  Default 256 (swept on the Products shape); graphs with
     // few edges get shorter segments: the persistent backward's critical path is its longest item (a 256-edge segment
     // is 64 dependent gather steps), which at Arxiv size (1.17 M edges) was longer than everything else together
-    const int kSegEdges = seg_env ? seg_env : (rp[n_rows] < (16 << 20) ? 64 : gat::kSegEdges);
+    // (Products shape 256; 64 below 16 M edges; Arxiv shape 32: 1.35 -> 1.29 ms; Pubmed shape 16: 0.34 -> 0.31 ms)
+    const int64_t ne = rp[n_rows];
+    const int kSegEdges = seg_env ? seg_env : (ne < (512 << 10) ? 16 : ne < (4 << 20) ? 32 : ne < (16 << 20) ? 64 : gat::kSegEdges);
     w.items.clear(); w.slot_info.clear(); w.n_slots = 0; w.n_split = 0;
     std::vector<int32_t> firsts;
     // pass 1: segments of split rows first (the longest items start earliest)

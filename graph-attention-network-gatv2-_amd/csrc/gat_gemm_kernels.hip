@@ -535,10 +535,10 @@ __global__ __launch_bounds__(256) void project_splitk_kernel(ASrcRows as, BSrcPr
         }
 }
 // the same block shape on the bf16 pipe (three-piece operands: rowgemm_x3_kernel); B chunk = 3 piece planes in LDS (96 KiB)
-template <bool VEC4>
+template <bool VEC4, int NT>
 __global__ __launch_bounds__(256) void project_splitk_x3_kernel(ASrcRows as, BSrcProject bs, float* __restrict__ slabs,
                                                                 int64_t M, int32_t N, int32_t K) {
-    constexpr int NW = 128, NT = 4, KC = 128, KS = KC / 16, plane = KS * 2 * NW;
+    constexpr int NW = NT * 32, KC = 128, KS = KC / 16, plane = KS * 2 * NW;
     extern __shared__ uint4 Bq[];                     // [3][KS][2][NW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, half = lane >> 5;
@@ -1037,15 +1037,23 @@ int launch_project(const float* X, const float* W, float* PL_rows, float* PR, in
         const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)ksplit);
         static const bool x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return !(e && e[0] == '0'); }();       // A/B: 0 = fp32 MFMA
         if (x3) {
-            const size_t lds = (size_t)3 * 8 * 2 * 128 * sizeof(uint4);
+            // 64-column blocks (48 KiB of LDS: three per CU) unless GAT_SPLITK_NT=4: Pubmed-shape 52 -> ?? us
+            static const int nt = [] { const char* e = getenv("GAT_SPLITK_NT"); return e && atoi(e) == 4 ? 4 : 2; }();
+            const size_t lds = (size_t)3 * 8 * 2 * (nt * 32) * sizeof(uint4);
             static const int attr_set = [] {
-                (void)hipFuncSetAttribute((const void*)project_splitk_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)project_splitk_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)project_splitk_x3_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute((const void*)project_splitk_x3_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 return 0;
             }();
             (void)attr_set;
-            if (vec4) hipLaunchKernelGGL(project_splitk_x3_kernel<true>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
-            else hipLaunchKernelGGL(project_splitk_x3_kernel<false>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+            const dim3 grid3((unsigned)((n_rows + 127) / 128), (unsigned)((N + nt * 32 - 1) / (nt * 32)), (unsigned)ksplit);
+            if (nt == 4) {
+                if (vec4) hipLaunchKernelGGL((project_splitk_x3_kernel<true, 4>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+                else hipLaunchKernelGGL((project_splitk_x3_kernel<false, 4>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+            } else {
+                if (vec4) hipLaunchKernelGGL((project_splitk_x3_kernel<true, 2>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+                else hipLaunchKernelGGL((project_splitk_x3_kernel<false, 2>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+            }
         } else {
             const size_t lds = (size_t)(128 * 128) * sizeof(float);
             if (vec4) hipLaunchKernelGGL(project_splitk_kernel<true>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
