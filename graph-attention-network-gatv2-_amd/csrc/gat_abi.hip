@@ -145,7 +145,7 @@ struct gat_ctx {
     int4* items = nullptr; int4* slot_info = nullptr;
     float* part_acc = nullptr; float* part_mz = nullptr;
     float* ga_partial = nullptr; int32_t ga_blocks = 0;
-    float* gw_scratch = nullptr;
+    float* gw_scratch = nullptr; std::vector<int64_t> gw_off;       // [L] first float of each layer's grad_w slab region
     float* hb_partial = nullptr;
     double* loss_partial = nullptr; int32_t* correct_partial = nullptr;
     float* loss_out = nullptr; int32_t* correct_out = nullptr;
@@ -337,9 +337,13 @@ static int ensure_buffers(gat_ctx* c) {
     } else {
         for (int l = 0; l < L; ++l) c->layers[l].stash = false;
     }
-    GAT_TRY(dalloc(c, &c->ga_partial, (int64_t)2048 * c->HDmax));      // >= any edge_backward_blocks()
-    int64_t gw = 1;
-    for (int l = 0; l < L; ++l) gw = std::max(gw, grad_w_scratch_floats(N, c->layers[l].F, c->layers[l].HD));
+    // one region per layer (grad_a block partials, grad_w slabs): their reductions are queued until the end of the
+    // backward and run as one launch (reduce_batch_flush), so a later layer must not overwrite an earlier layer's slabs
+    GAT_TRY(dalloc(c, &c->ga_partial, (int64_t)L * 2048 * c->HDmax));  // per layer >= any edge_backward_blocks()
+    int64_t gw = 0;
+    c->gw_off.assign((size_t)L, 0);
+    for (int l = 0; l < L; ++l) { c->gw_off[(size_t)l] = gw; gw += grad_w_scratch_floats(N, c->layers[l].F, c->layers[l].HD); }
+    gw = std::max<int64_t>(gw, 1);
     if (c->Xtab) gw = std::max(gw, grad_w_scratch_floats(T, c->layers[0].F, c->layers[0].HD));
     for (int l = 0; l < L; ++l) gw = std::max(gw, project_scratch_floats(l == 0 && c->Xtab ? T : N, c->layers[l].F, c->layers[l].HD));   // split-K projection (few rows, long K)
     GAT_TRY(dalloc(c, &c->gw_scratch, gw));
@@ -757,13 +761,16 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
     a.stash = stash ? c->stash : nullptr; a.gfull = stash ? c->gfull : nullptr; a.stash_spare = (uint32_t)c->n_edges;
     // last layer: the pull pass rebuilds g from gH and the decision bytes (GAT_PULL_LAST=0: gathers gfull like a hidden layer, A/B)
-    static const bool pull_last = [] { const char* e = getenv("GAT_PULL_LAST"); return !(e && e[0] == '0'); }();
-    const bool last_g = stash && a.gh != nullptr && c->hbits != nullptr && !bf16(c) && pull_last;
+    // Worth it only when the g rows the pull pass would gather do not stay in the caches (Products shape 627 MB: 2.73 -> 2.29 ms;
+    // Arxiv shape 43 MB: the extra loads per slot cost more than the smaller rows save, 1.31 -> 1.25 ms per step without)
+    static const int pull_last = [] { const char* e = getenv("GAT_PULL_LAST"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool big_rows = (int64_t)c->n_rows * y.H * y.D * 4 > ((int64_t)128 << 20);
+    const bool last_g = stash && a.gh != nullptr && c->hbits != nullptr && !bf16(c) && (pull_last >= 0 ? pull_last == 1 : big_rows);
     a.hbits = last_g ? c->hbits : nullptr;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots; a.n_split = c->work.n_split;
     a.part_acc = c->part_acc;
     a.dbg = c->dbg;
-    a.ga_partial = c->ga_partial; a.n_rows = c->n_rows; a.n_table = c->n_table; a.bf16 = bf16(c); a.H = y.H; a.D = y.D;
+    a.ga_partial = c->ga_partial + (int64_t)l * 2048 * c->HDmax; a.n_rows = c->n_rows; a.n_table = c->n_table; a.bf16 = bf16(c); a.H = y.H; a.D = y.D;
     a.ga_blocks = edge_fast_path(y.H, y.D, c->n_table) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr, bf16(c), stash)
                                            : edge_backward_blocks(c->n_rows * 4, y.H, y.D, false, false, false);
     a.slope = c->cfg.negative_slope;
@@ -783,7 +790,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
                                c->gpl_heavy, c->n_gpl_heavy, c->gpl_part, c->stream));
     }
     Scope t(c, GAT_K_MISC);
-    return launch_reduce_partials_add(c->ga_partial, a.ga_blocks, y.HD, ga_of(c, l), c->stream);
+    return launch_reduce_partials_add(a.ga_partial, a.ga_blocks, y.HD, ga_of(c, l), c->stream);
 }
 
 int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
@@ -796,7 +803,7 @@ int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
             GAT_TRY(launch_grad_w(c->gPL, nullptr, c->Xtab, gW_of(c, l), c->gw_scratch, c->n_table, y.F, y.HD, kPartLeft, c->stream));
             GAT_TRY(launch_grad_w(nullptr, c->gPR, c->X0, gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, kPartRight, c->stream));
         } else {
-            GAT_TRY(launch_grad_w(gPL_rows, c->gPR, Xin_of(c, l), gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, kPartBoth, c->stream));
+            GAT_TRY(launch_grad_w(gPL_rows, c->gPR, Xin_of(c, l), gW_of(c, l), c->gw_scratch + c->gw_off[(size_t)l], c->n_rows, y.F, y.HD, kPartBoth, c->stream));
         }
     }
     if (l == 0) return 0;                                             // E:1528
@@ -952,10 +959,33 @@ static int reduce_end(gat_ctx* c, int64_t count) {          // count: n_params, 
     Scope t(c, GAT_K_MISC);
     return launch_reduce_partials_add(c->grads_prev, 1, c->nW + c->nA + c->nWo, c->grads, c->stream);
 }
+// Slab reductions of the backward (grad_Wo, grad_a and grad_W of every layer) and the result pack as one launch at the
+// end (ReduceBatch).  Not with replicated layer-0 input: its two grad_w launches share one slab region.  GAT_REDUCE_BATCH=0: A/B.
+struct BatchScope {
+    bool on;
+    explicit BatchScope(gat_ctx* c) {
+        static const bool env_on = [] { const char* e = getenv("GAT_REDUCE_BATCH"); return !(e && e[0] == '0'); }();
+        on = env_on && !c->Xtab;
+        if (on) reduce_batch_begin();
+    }
+    int finish(gat_ctx* c, bool pack) {
+        float* tail = c->grads + c->nW + c->nA + c->nWo;
+        if (!on) return pack ? launch_pack_result(c->loss_out, c->correct_out, tail, c->stream) : 0;
+        on = false;
+        if (pack) reduce_batch_pack(c->loss_out, c->correct_out, tail);
+        Scope t(c, GAT_K_MISC);
+        return reduce_batch_flush(c->stream);
+    }
+    ~BatchScope() { if (on) reduce_batch_abort(); }       // error return in between: nothing stays queued
+};
 int gat_backward(gat_ctx* c) {
     GAT_TRY(check_step(c, "gat_backward"));
     GAT_TRY(reduce_begin(c));
-    GAT_TRY(backward_phases(c));
+    {
+        BatchScope batch(c);
+        GAT_TRY(backward_phases(c));
+        GAT_TRY(batch.finish(c, false));
+    }
     return reduce_end(c, c->nW + c->nA + c->nWo);
 }
 // The whole step as ONE graph launch: small graphs (Cora / Pubmed / Arxiv shapes) are launch-bound — ~25
@@ -973,6 +1003,7 @@ static void graph_drop(gat_ctx* c) {
 }
 static int step_body(gat_ctx* c) {
     GAT_TRY(forward_phases(c));
+    BatchScope batch(c);
     if (fused_head(c)) {
         GAT_TRY(head_step(c));
         GAT_TRY(backward_phases(c, true));
@@ -980,7 +1011,7 @@ static int step_body(gat_ctx* c) {
         GAT_TRY(gat_head_forward(c, nullptr, nullptr));
         GAT_TRY(backward_phases(c));
     }
-    return launch_pack_result(c->loss_out, c->correct_out, c->grads + c->nW + c->nA + c->nWo, c->stream);
+    return batch.finish(c, true);
 }
 static int step_graph(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
     const int64_t np = c->nW + c->nA + c->nWo;

@@ -50,6 +50,45 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
     }
 }
 
+// every queued reduction in one launch (ReduceBatch); block -> job by the jobs' first-block prefix; one extra block
+// packs {loss, correct} like pack_result_kernel
+__global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceBatch B) {
+    __shared__ float part[16][64];
+    if ((int)blockIdx.x >= B.blocks) {
+        if (threadIdx.x == 0) {
+            const int32_t c = *B.correct;
+            B.dst3[0] = *B.loss; B.dst3[1] = (float)(c & 4095); B.dst3[2] = (float)(c >> 12);
+        }
+        return;
+    }
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < B.n && (int)blockIdx.x >= B.jobs[i].block0) j = i;
+    const ReduceJob J = B.jobs[j];
+    const int q = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t idx = (int64_t)((int)blockIdx.x - J.block0) * 64 + q;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < J.width) {
+        int z = sl;
+        for (; z + 48 < J.nslabs; z += 64) {
+            s0 += J.slabs[(int64_t)z * J.width + idx];
+            s1 += J.slabs[(int64_t)(z + 16) * J.width + idx];
+            s2 += J.slabs[(int64_t)(z + 32) * J.width + idx];
+            s3 += J.slabs[(int64_t)(z + 48) * J.width + idx];
+        }
+        for (; z < J.nslabs; z += 16) s0 += J.slabs[(int64_t)z * J.width + idx];
+    }
+    part[sl][q] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && idx < J.width) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += part[w][q];
+        const int64_t o = J.HD != 0 ? MapGradW{J.HD, J.F, J.c_base}(idx) : idx;
+        J.out[o] += tot;
+    }
+}
+
 // ---- output head ----------------------------------------------------------------------------------------------
 // C12+C13 (E:463-537): z = Wo·H_L[n]; y = exp(z-max)/(sum+1e-8) (double divide, E:140);
 // loss_n = -log(max(y[label],1e-12)); correct_n = (argmax == label).  One thread per node, the
@@ -461,9 +500,34 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* g, int64_t n, co
 }  // namespace
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
+static thread_local ReduceBatch t_batch;
+static thread_local bool t_batch_on = false;
+void reduce_batch_begin() { t_batch = ReduceBatch{}; t_batch_on = true; }
+void reduce_batch_abort() { t_batch_on = false; }
+void reduce_batch_pack(const float* loss, const int32_t* correct, float* dst3) {
+    t_batch.loss = loss; t_batch.correct = correct; t_batch.dst3 = dst3;
+}
+static bool reduce_batch_push(const float* slabs, int32_t nslabs, int64_t width, float* out, int32_t HD, int32_t F, int32_t c_base) {
+    if (!t_batch_on || t_batch.n >= 8 || width <= 0) return false;
+    ReduceJob& j = t_batch.jobs[t_batch.n++];
+    j = ReduceJob{slabs, out, width, nslabs, HD, F, c_base, t_batch.blocks};
+    t_batch.blocks += (int32_t)((width + 63) / 64);
+    return true;
+}
+int reduce_batch_flush(hipStream_t s) {
+    if (!t_batch_on) return 0;
+    t_batch_on = false;
+    const int extra = t_batch.dst3 != nullptr ? 1 : 0;
+    if (t_batch.blocks + extra == 0) return 0;
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(t_batch.blocks + extra)), dim3(1024), 0, s, t_batch);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_reduce_gradw(const float* slabs, int32_t ksplit, int32_t HD, int32_t F, int32_t c_base, int32_t M,
                         float* gradW, hipStream_t s) {
     const int64_t width = (int64_t)M * F;
+    if (reduce_batch_push(slabs, ksplit, width, gradW, HD, F, c_base)) return 0;
     hipLaunchKernelGGL((reduce_slabs_kernel<MapGradW>), dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, s, slabs,
                        ksplit, width, gradW, MapGradW{HD, F, c_base});
     GAT_HIP(hipGetLastError());
@@ -472,6 +536,7 @@ int launch_reduce_gradw(const float* slabs, int32_t ksplit, int32_t HD, int32_t 
 
 int launch_reduce_partials_add(const float* partial, int32_t nblocks, int64_t width, float* out, hipStream_t s) {
     if (width <= 0) return 0;
+    if (reduce_batch_push(partial, nblocks, width, out, 0, 0, 0)) return 0;
     hipLaunchKernelGGL((reduce_slabs_kernel<MapIdentity>), dim3((unsigned)((width + 63) / 64)), dim3(1024), 0, s,
                        partial, nblocks, width, out, MapIdentity{});
     GAT_HIP(hipGetLastError());

@@ -173,6 +173,16 @@ int comm_create_rccl(int world, int rank, const void* id_bytes, Comm** out);
 int comm_create_host(int world, int rank, const char* shm_name, int64_t bytes_per_rank, Comm** out);
 
 int launch_pack_result(const float* loss, const int32_t* correct, float* dst3, hipStream_t s);
+// Deferred slab reductions.  Between reduce_batch_begin() and reduce_batch_flush() (same host thread) launch_reduce_gradw /
+// launch_reduce_partials_add queue their job instead of launching it, and the flush runs all of them — plus the result
+// pack, if asked for — as ONE kernel: on Cora / Pubmed-size graphs every launch is ~5 us of a ~250 us step.  The slabs
+// of a queued job must stay untouched until the flush (per-layer scratch regions: gat_abi.hip).
+struct ReduceJob { const float* slabs; float* out; int64_t width; int32_t nslabs, HD, F, c_base, block0; };   // HD == 0: out[idx]
+struct ReduceBatch { ReduceJob jobs[8]; int32_t n, blocks; const float* loss; const int32_t* correct; float* dst3; };
+void reduce_batch_begin();
+void reduce_batch_abort();
+void reduce_batch_pack(const float* loss, const int32_t* correct, float* dst3);
+int reduce_batch_flush(hipStream_t s);
 int launch_reduce_partials_add(const float* partial, int32_t nblocks, int64_t width, float* out,
                                hipStream_t s);
 
