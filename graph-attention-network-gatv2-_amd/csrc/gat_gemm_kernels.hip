@@ -1,6 +1,5 @@
 // gat_gemm_kernels.hip — the dense W_l / W_r feature projections of the GATv2 layer and their
-// backward, as exact-fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, so the
-// numerics are those of the reference's float loops up to summation order).
+// backward as MFMA GEMMs with fp32 accuracy.
 //
 // The reference recomputes W·x inside every per-edge thread (E:303-316, 415-420, 636-640,
 // 752-761, 848-853).  Here it is computed once per node:
@@ -9,13 +8,16 @@
 //   grad_w  : gradW_left += gPL^T · X,  gradW_right += gPR^T · X       (E:770-782 summed over edges)
 // W stays in the reference layout [H*D][2F] (row j: cols 0..F-1 left, F..2F-1 right).
 //
-// Shapes are skinny: M = nodes (millions), K and N <= ~128.  project / grad_x therefore keep the
-// whole B operand resident in LDS for the lifetime of a persistent block and stream A straight
-// from HBM into MFMA fragments (one float4 per lane covers 4 k-steps: lane (i, half) reads
-// A[i][kb+4*half .. +3]; MFMA j' of the step pairs element j' with B row kb+4*half+j').  grad_w
-// reduces over the node dimension: node tiles are staged through double-buffered LDS in their
-// memory layout (which already is the k-major layout the fragments want), split-K over blocks,
-// slabs summed in fixed order.
+// Arithmetic (round 2): the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) runs at 1/16 of
+// the bf16 rate and made every kernel here MFMA-bound at Products size.  The default kernels (*_x3_*) cut each fp32
+// operand EXACTLY into three bf16 pieces and run six bf16 MFMAs per product with fp32 accumulation: error per product
+// < 2^-23, measured error of a K = 100 dot product 6.9e-7 x sum|a||b| against 8.5e-7 for the reference's own fp32 fma
+// chain (tests/test_dense_precision.py).  The fp32-MFMA kernels stay as the A/B (GAT_GEMM_X3=0, GAT_GRADW_X3=0).
+//
+// Shapes are skinny: M = nodes (millions), K and N <= ~128.  project / grad_x keep the whole B operand resident in
+// LDS for the lifetime of a persistent block and stream A straight from HBM into MFMA fragments.  grad_w reduces
+// over the node dimension: node tiles are staged through LDS in their memory layout and read back transposed
+// (ds_read_b64_tr_b16), split-K over the resident blocks, slabs summed in fixed order.
 #include "gat_internal.h"
 
 #include <cstdlib>
