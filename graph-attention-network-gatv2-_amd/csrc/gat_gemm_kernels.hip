@@ -126,6 +126,17 @@ int64_t resident_blocks(const void* fn, size_t dyn_lds, int threads) {
     return cache[key] = (int64_t)per_cu * (cus > 0 ? cus : 256);
 }
 
+// dynamic LDS beyond 64 KiB must be allowed per kernel AND per device (a process may drive several); cheap after the first call
+static void allow_big_lds(const void* fn) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, bool> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    bool& d = done[std::make_pair(fn, dev)];
+    if (!d) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); d = true; }
+}
+
 namespace {
 
 // C[M][N] = A[M][K] · B[K][N].  256 threads = 4 waves, each wave owns 32 rows x (NT*32) columns of a
@@ -636,10 +647,7 @@ int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, 
 #define GAT_ROWGEMM_X3(NT_, W_, V_)                                                                           \
     {                                                                                                         \
         auto kern = rowgemm_x3_kernel<NT_, W_, V_, AS, BS, EP>;                                               \
-        static const int attr_set = [&] {                                                                     \
-            return (int)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        }();                                                                                                  \
-        (void)attr_set;                                                                                       \
+        if (lds3 > 64 * 1024) allow_big_lds((const void*)kern);                                               \
         const int64_t nt_ = (M + W_ * 32 - 1) / (W_ * 32);                                                    \
         int64_t res = resident_blocks((const void*)kern, lds3, W_ * 64);                                    \
         const dim3 grid((unsigned)(nt_ < res ? nt_ : res), (unsigned)((N + NW - 1) / NW));                    \
@@ -1039,15 +1047,10 @@ int launch_project(const float* X, const float* W, float* PL_rows, float* PR, in
         const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)ksplit);
         static const bool x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return !(e && e[0] == '0'); }();       // A/B: 0 = fp32 MFMA
         if (x3) {
-            // 64-column blocks (48 KiB of LDS: three per CU) unless GAT_SPLITK_NT=4: Pubmed-shape 52 -> ?? us
+            // 64-column blocks (48 KiB of LDS: three per CU) unless GAT_SPLITK_NT=4: Pubmed-shape 0.311 -> 0.302 ms per step
             static const int nt = [] { const char* e = getenv("GAT_SPLITK_NT"); return e && atoi(e) == 4 ? 4 : 2; }();
             const size_t lds = (size_t)3 * 8 * 2 * (nt * 32) * sizeof(uint4);
-            static const int attr_set = [] {
-                (void)hipFuncSetAttribute((const void*)project_splitk_x3_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute((const void*)project_splitk_x3_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                return 0;
-            }();
-            (void)attr_set;
+            if (nt == 4) { allow_big_lds((const void*)project_splitk_x3_kernel<true, 4>); allow_big_lds((const void*)project_splitk_x3_kernel<false, 4>); }
             const dim3 grid3((unsigned)((n_rows + 127) / 128), (unsigned)((N + nt * 32 - 1) / (nt * 32)), (unsigned)ksplit);
             if (nt == 4) {
                 if (vec4) hipLaunchKernelGGL((project_splitk_x3_kernel<true, 4>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
