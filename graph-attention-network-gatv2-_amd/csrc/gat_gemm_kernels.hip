@@ -630,27 +630,37 @@ __global__ __launch_bounds__(256) void project_reduce_kernel(const float* __rest
 // rows few enough that the streaming kernel would leave most CUs idle, K long enough to be worth splitting
 static bool project_wants_splitk(int64_t M, int32_t N, int32_t K) {
     static const bool off = [] { const char* e = getenv("GAT_PROJECT_SPLITK"); return e && e[0] == '0'; }();     // A/B
-    return !off && K > 128 && ((M + 127) / 128) * ((N + 127) / 128) < 256;
+    static const int x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return e ? atoi(e) : -1; }();
+    static const int kmax_env = [] { const char* e = getenv("GAT_X3_KMAX"); return e ? atoi(e) : 128; }();            // A/B: 512 = row-streaming kernel up to K = 512
+    const int kmax = x3 != 0 ? kmax_env : 128;       // up to here the row-streaming kernel keeps all of K in LDS (run_rowgemm)
+    return !off && K > kmax && ((M + 127) / 128) * ((N + 127) / 128) < 256;
 }
 
 template <class AS, class BS, class EP>
 int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, int32_t K, bool vec4, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int NT = N > 64 ? 4 : (N > 32 ? 2 : 1);
-    const int NW = NT * 32;
-    const int kc_lds = ((K < kKC ? K : kKC) + 7) & ~7;
-    const size_t lds = (size_t)kc_lds * NW * sizeof(float);
-    static const int x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return e ? atoi(e) : 8; }();   // A/B: 0 = fp32 MFMA; 4 / 8 = waves per block
-    if (x3 != 0 && K <= 128) {
+    int NT = N > 64 ? 4 : (N > 32 ? 2 : 1);
+    static const int x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return e ? atoi(e) : -1; }();  // A/B: 0 = fp32 MFMA; 4 / 8 = force waves per block
+    // B (all of K x the block's columns, three piece planes) must fit in LDS: K <= 128 with 128 columns per block.  Narrower
+    // column slices would take K up to 512 (the Pubmed shape's 500: four slices, A re-read per slice from L2), but measured
+    // there it only ties the split-K kernel (0.245-0.259 vs 0.252 ms per step) and one 500-long accumulation chain is less
+    // accurate than four 128-long ones: split-K stays the default beyond K = 128 (GAT_X3_KMAX=512 is the A/B).
+    int NT3 = NT;
+    while (NT3 > 1 && (size_t)3 * ((K + 15) / 16) * 2 * (NT3 * 32) * sizeof(uint4) > 100 * 1024) NT3 >>= 1;
+    if (x3 != 0 && (size_t)3 * ((K + 15) / 16) * 2 * (NT3 * 32) * sizeof(uint4) <= 100 * 1024) {
+        NT = NT3;
+        const int NW = NT * 32;
         const int KS = (K + 15) / 16;
         const size_t lds3 = (size_t)3 * KS * 2 * NW * sizeof(uint4);
+        const int ny = (N + NW - 1) / NW;
 #define GAT_ROWGEMM_X3(NT_, W_, V_)                                                                           \
     {                                                                                                         \
         auto kern = rowgemm_x3_kernel<NT_, W_, V_, AS, BS, EP>;                                               \
         if (lds3 > 64 * 1024) allow_big_lds((const void*)kern);                                               \
         const int64_t nt_ = (M + W_ * 32 - 1) / (W_ * 32);                                                    \
-        int64_t res = resident_blocks((const void*)kern, lds3, W_ * 64);                                    \
-        const dim3 grid((unsigned)(nt_ < res ? nt_ : res), (unsigned)((N + NW - 1) / NW));                    \
+        int64_t res = resident_blocks((const void*)kern, lds3, W_ * 64) / ny;     /* persistent: one round */  \
+        if (res < 1) res = 1;                                                                                 \
+        const dim3 grid((unsigned)(nt_ < res ? nt_ : res), (unsigned)ny);                                     \
         hipLaunchKernelGGL(kern, grid, dim3(W_ * 64), lds3, s, as, bs, ep, M, N, K);                           \
     }
 #define GAT_ROWGEMM_X3_NT(W_, V_)                                                                             \
@@ -662,6 +672,9 @@ int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, 
         GAT_HIP(hipGetLastError());
         return 0;
     }
+    const int NW = NT * 32;
+    const int kc_lds = ((K < kKC ? K : kKC) + 7) & ~7;
+    const size_t lds = (size_t)kc_lds * NW * sizeof(float);
     const int64_t ntiles = (M + 127) / 128;
     if constexpr (!EP::kTwoPhase) {
         static const bool pipe = [] { const char* e = getenv("GAT_GEMM_PIPE"); return !(e && e[0] == '0'); }();   // A/B

@@ -5,7 +5,7 @@ These tests hold the kernels to that, against an fp64 product of the same fp32 i
 itself sets: its per-edge float loop (E:303-316) is a chain of K fused multiply-adds, emulated here in numpy on the same
 data (`_chain_ratio`).  With  ratio = max |got - exact| / sum_k |a_k| |b_k|  over all outputs:
 
-    ratio(kernel) <= 1.5 * ratio(fp32 fma chain) + 1e-7     and     ratio(kernel) <= 1e-6
+    ratio(kernel) <= 1.5 * ratio(fp32 fma chain) + 1e-7     and     ratio(kernel) <= 1e-6 * max(1, sqrt(K / 100))
 
 (measured on the K = 100 case: kernel 6.9e-7, chain 8.5e-7).  One bf16 pass (2^-9 per product) misses this by three
 orders of magnitude, a three-term bf16x3 (2^-17, biased) by one.
@@ -68,7 +68,8 @@ def test_projection_is_an_fp32_accurate_product(pkg, orc, n, f, heads, outdims, 
         scale = np.abs(x64) @ np.abs(w).T
         r = _ratio(got, exact, scale)
         rc = _chain_ratio(x, w.astype(np.float32), exact, scale)
-        assert r <= BOUND and r <= 1.5 * rc + 1e-7, f"{what}: {name} error {r:.3g} x sum|x||w| (fp32 fma chain: {rc:.3g})"
+        assert r <= BOUND * max(1.0, (f / 100) ** 0.5) and r <= 1.5 * rc + 1e-7, \
+            f"{what}: {name} error {r:.3g} x sum|x||w| (fp32 fma chain: {rc:.3g})"
     # and the bound means something: rounding the operands to bf16 once misses it by orders of magnitude
     xb = (x.view(np.uint32) & 0xFFFF0000).view(np.float32).astype(np.float64)
     r_bf16 = _ratio(xb @ Wl[:, :f].T, x64 @ Wl[:, :f].T, np.abs(x64) @ np.abs(Wl[:, :f]).T)
@@ -110,4 +111,5 @@ def test_grad_w_is_an_fp32_accurate_product(pkg, orc, n, f, what):
     r = _ratio(gW[:, :f], exact, scale)
     # K = n nodes, summed in slabs of a few hundred nodes and then across slabs: more accurate than one chain over all nodes
     rc = _chain_ratio(np.ascontiguousarray(gpl.T), np.ascontiguousarray(x.T), exact, scale)
-    assert r <= BOUND and r <= 1.5 * rc + 1e-7, f"{what}: gradW_left error {r:.3g} x sum|g||x| (fp32 fma chain: {rc:.3g})"
+    assert r <= BOUND * max(1.0, (n / 100) ** 0.5) and r <= 1.5 * rc + 1e-7, \
+        f"{what}: gradW_left error {r:.3g} x sum|g||x| (fp32 fma chain: {rc:.3g})"
