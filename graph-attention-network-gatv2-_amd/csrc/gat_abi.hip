@@ -968,11 +968,13 @@ struct BatchScope {
         on = env_on && !c->Xtab;
         if (on) reduce_batch_begin();
     }
-    int finish(gat_ctx* c, bool pack) {
+    // host_tail: pinned copy of the packed result written by the same kernel (*host_done = it was: no copy node needed)
+    int finish(gat_ctx* c, bool pack, float* host_tail = nullptr, bool* host_done = nullptr) {
         float* tail = c->grads + c->nW + c->nA + c->nWo;
+        if (host_done) *host_done = on && pack && host_tail != nullptr;
         if (!on) return pack ? launch_pack_result(c->loss_out, c->correct_out, tail, c->stream) : 0;
         on = false;
-        if (pack) reduce_batch_pack(c->loss_out, c->correct_out, tail);
+        if (pack) reduce_batch_pack(c->loss_out, c->correct_out, tail, host_tail);
         Scope t(c, GAT_K_MISC);
         return reduce_batch_flush(c->stream);
     }
@@ -1001,7 +1003,8 @@ static void graph_drop(gat_ctx* c) {
     if (c->graph_state == 2) c->graph_state = 1;
     c->graph_warm = 0;
 }
-static int step_body(gat_ctx* c) {
+static int step_body(gat_ctx* c, float* host_tail = nullptr, bool* host_done = nullptr) {
+    if (host_done) *host_done = false;
     GAT_TRY(forward_phases(c));
     BatchScope batch(c);
     if (fused_head(c)) {
@@ -1011,7 +1014,7 @@ static int step_body(gat_ctx* c) {
         GAT_TRY(gat_head_forward(c, nullptr, nullptr));
         GAT_TRY(backward_phases(c));
     }
-    return batch.finish(c, true);
+    return batch.finish(c, true, host_tail, host_done);
 }
 static int step_graph(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
     const int64_t np = c->nW + c->nA + c->nWo;
@@ -1024,8 +1027,9 @@ static int step_graph(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
         if (!c->pinned_tail) GAT_HIP(hipHostMalloc((void**)&c->pinned_tail, 4 * sizeof(float)));
         GAT_HIP(hipStreamSynchronize(c->stream));
         GAT_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        int rc = step_body(c);
-        if (rc == 0 && hipMemcpyAsync(c->pinned_tail, c->grads + np, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        bool host_done = false;                             // the batch kernel's pack block wrote the pinned copy itself
+        int rc = step_body(c, c->pinned_tail, &host_done);
+        if (rc == 0 && !host_done && hipMemcpyAsync(c->pinned_tail, c->grads + np, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
             rc = fail(GAT_E_STATE, "gat_step_graph: capture of the result copy failed");
         hipGraph_t g = nullptr;
         const hipError_t e = hipStreamEndCapture(c->stream, &g);

@@ -54,10 +54,22 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
 // packs {loss, correct} like pack_result_kernel
 __global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceBatch B) {
     __shared__ float part[16][64];
-    if ((int)blockIdx.x >= B.blocks) {
-        if (threadIdx.x == 0) {
-            const int32_t c = *B.correct;
-            B.dst3[0] = *B.loss; B.dst3[1] = (float)(c & 4095); B.dst3[2] = (float)(c >> 12);
+    if ((int)blockIdx.x >= B.blocks) {                   // the extra block: head finalize (as head_finalize_kernel), then the pack
+        if (threadIdx.x >= 64) return;
+        float lossv = 0.f; int32_t corrv = 0;
+        if (B.fin_loss != nullptr) {
+            double l = 0.0; int c = 0;
+            for (int i = threadIdx.x; i < B.fin_n; i += 64) { l += B.fin_loss[i]; c += B.fin_corr[i]; }
+            for (int off = 32; off > 0; off >>= 1) { l += __shfl_down(l, off); c += __shfl_down(c, off); }
+            lossv = (float)l; corrv = c;
+            if (threadIdx.x == 0) { *B.fin_loss_out = lossv; *B.fin_corr_out = corrv; }
+        } else if (threadIdx.x == 0 && B.dst3 != nullptr) {
+            lossv = *B.loss; corrv = *B.correct;
+        }
+        if (threadIdx.x == 0 && B.dst3 != nullptr) {
+            const float v0 = lossv, v1 = (float)(corrv & 4095), v2 = (float)(corrv >> 12);
+            B.dst3[0] = v0; B.dst3[1] = v1; B.dst3[2] = v2;
+            if (B.dst3_host != nullptr) { B.dst3_host[0] = v0; B.dst3_host[1] = v1; B.dst3_host[2] = v2; }
         }
         return;
     }
@@ -504,8 +516,13 @@ static thread_local ReduceBatch t_batch;
 static thread_local bool t_batch_on = false;
 void reduce_batch_begin() { t_batch = ReduceBatch{}; t_batch_on = true; }
 void reduce_batch_abort() { t_batch_on = false; }
-void reduce_batch_pack(const float* loss, const int32_t* correct, float* dst3) {
-    t_batch.loss = loss; t_batch.correct = correct; t_batch.dst3 = dst3;
+void reduce_batch_pack(const float* loss, const int32_t* correct, float* dst3, float* dst3_host) {
+    t_batch.loss = loss; t_batch.correct = correct; t_batch.dst3 = dst3; t_batch.dst3_host = dst3_host;
+}
+bool reduce_batch_finalize(const double* lp, const int32_t* cp, int32_t nb, float* loss_out, int32_t* correct_out) {
+    if (!t_batch_on || t_batch.fin_loss != nullptr) return false;
+    t_batch.fin_loss = lp; t_batch.fin_corr = cp; t_batch.fin_n = nb; t_batch.fin_loss_out = loss_out; t_batch.fin_corr_out = correct_out;
+    return true;
 }
 static bool reduce_batch_push(const float* slabs, int32_t nslabs, int64_t width, float* out, int32_t HD, int32_t F, int32_t c_base) {
     if (!t_batch_on || t_batch.n >= 8 || width <= 0) return false;
@@ -517,7 +534,7 @@ static bool reduce_batch_push(const float* slabs, int32_t nslabs, int64_t width,
 int reduce_batch_flush(hipStream_t s) {
     if (!t_batch_on) return 0;
     t_batch_on = false;
-    const int extra = t_batch.dst3 != nullptr ? 1 : 0;
+    const int extra = (t_batch.dst3 != nullptr || t_batch.fin_loss != nullptr) ? 1 : 0;
     if (t_batch.blocks + extra == 0) return 0;
     hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(t_batch.blocks + extra)), dim3(1024), 0, s, t_batch);
     GAT_HIP(hipGetLastError());
@@ -599,9 +616,11 @@ int launch_head_step(const HeadArgs& f, const HeadBwdArgs& b, hipStream_t s) {
     else if (b.DL == 8) hipLaunchKernelGGL(head_step_kernel<8>, dim3(blocks), dim3(256), lds, s, f, b, ldz);
     else hipLaunchKernelGGL(head_step_kernel<16>, dim3(blocks), dim3(256), lds, s, f, b, ldz);
     GAT_HIP(hipGetLastError());
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(64), 0, s, f.loss_partial, f.correct_partial, blocks,
-                       f.loss_out, f.correct_out);
-    GAT_HIP(hipGetLastError());
+    if (!reduce_batch_finalize(f.loss_partial, f.correct_partial, blocks, f.loss_out, f.correct_out)) {
+        hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(64), 0, s, f.loss_partial, f.correct_partial, blocks,
+                           f.loss_out, f.correct_out);
+        GAT_HIP(hipGetLastError());
+    }
     return launch_reduce_partials_add(b.partial, blocks, (int64_t)b.C * b.DL, b.gradWo, s);
 }
 int launch_pack_result(const float* loss, const int32_t* correct, float* dst3, hipStream_t s) {

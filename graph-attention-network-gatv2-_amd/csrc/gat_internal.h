@@ -178,10 +178,16 @@ int launch_pack_result(const float* loss, const int32_t* correct, float* dst3, h
 // pack, if asked for — as ONE kernel: on Cora / Pubmed-size graphs every launch is ~5 us of a ~250 us step.  The slabs
 // of a queued job must stay untouched until the flush (per-layer scratch regions: gat_abi.hip).
 struct ReduceJob { const float* slabs; float* out; int64_t width; int32_t nslabs, HD, F, c_base, block0; };   // HD == 0: out[idx]
-struct ReduceBatch { ReduceJob jobs[8]; int32_t n, blocks; const float* loss; const int32_t* correct; float* dst3; };
+struct ReduceBatch {
+    ReduceJob jobs[8]; int32_t n, blocks;
+    const float* loss; const int32_t* correct; float* dst3; float* dst3_host;      // result pack (dst3_host: optional pinned copy)
+    const double* fin_loss; const int32_t* fin_corr; int32_t fin_n; float* fin_loss_out; int32_t* fin_corr_out;   // head finalize
+};
 void reduce_batch_begin();
 void reduce_batch_abort();
-void reduce_batch_pack(const float* loss, const int32_t* correct, float* dst3);
+void reduce_batch_pack(const float* loss, const int32_t* correct, float* dst3, float* dst3_host);
+// the output head's block partials -> {loss, #correct} (head_finalize_kernel) inside the batch kernel's pack block; false = not queued
+bool reduce_batch_finalize(const double* loss_partial, const int32_t* correct_partial, int32_t nblocks, float* loss_out, int32_t* correct_out);
 int reduce_batch_flush(hipStream_t s);
 int launch_reduce_partials_add(const float* partial, int32_t nblocks, int64_t width, float* out,
                                hipStream_t s);
