@@ -829,7 +829,7 @@ static int check_step(gat_ctx* c, const char* who) {
 // projected in K row chunks on the compute stream; as soon as chunk k exists, its part of every rank's table slice is
 // exchanged on a second stream, while chunk k+1 is being projected.  The edge pass waits for the last part.  Chunk
 // boundaries are the same slice coordinates on every rank (multiples of 128 rows of max_rows), so the parts have fixed
-// counts.  Every PL / PR row is produced by the same fmaf chain as in one launch: results are bitwise those of the
+// counts.  Every PL / PR row is produced by the same sequence of matrix instructions as in one launch: results are bitwise those of the
 // unchunked exchange (tests/test_shard.py).  What can hide behind the exchange this way is the projection itself; the
 // edge pass needs the whole table.
 static int forward_exchange_pipelined(gat_ctx* c, int l) {
