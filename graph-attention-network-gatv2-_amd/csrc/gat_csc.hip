@@ -285,6 +285,15 @@ template <int N> struct PullVec;
 template <> struct PullVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <> struct PullVec<4> { typedef float T __attribute__((ext_vector_type(4))); };
 
+// write-once output rows: streaming stores (see gat_edge_kernels.hip; GAT_NT_STORES: experiment)
+template <class T>
+__device__ __forceinline__ void stream_store(T* p, const T& v) {
+#ifdef GAT_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 // LASTD > 0 (last layer, D = LASTD): g[dst][c] = gh[dst][c % D] * LReLU'(h_pre[dst][c]) / H  (E:598-603) is rebuilt from
 // gh [n_rows][D] and the per-lane decision byte hbits [n_rows][HD/N] — 48 B gathered per edge from two small tables
 // (98 MB + 39 MB at the Products shape: cache-resident) instead of a 256-B row of g.
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = 0.f;
     }
-    if (lane < LPE) *reinterpret_cast<V*>(gPL + s * HD + cp * N) = acc;
+    if (lane < LPE) stream_store(reinterpret_cast<V*>(gPL + s * HD + cp * N), acc);
 }
 
 template <int HD, int N, bool BF, int LASTD>
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(256) void gpl_pull3_kernel(const int4* __restrict__
     }
     if (src < 0) return;
     float* dst = pslot < 0 ? gPL + (int64_t)src * HD : part + (int64_t)pslot * HD;
-    *reinterpret_cast<V*>(dst + cp * N) = acc;
+    stream_store(reinterpret_cast<V*>(dst + cp * N), acc);
 }
 
 // cdst[pos[e]] = row of CSR edge e (binary search in row_ptr, as csr_to_coo_kernel)

@@ -564,6 +564,16 @@ __device__ __forceinline__ vnf<N> gather_row_n(const float* __restrict__ table, 
 #endif
     }
 }
+// write-once rows and records that this kernel never reads back: streaming stores keep them from displacing the gathered
+// source rows in L2 (GAT_NT_STORES: experiment)
+template <class T>
+__device__ __forceinline__ void stream_store(T* p, const T& v) {
+#ifdef GAT_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 template <int HD, int N, bool BF>
 __device__ __forceinline__ void store_row_n(float* __restrict__ msg, int slot, int cp, vnf<N> v) {
     if constexpr (BF) {
@@ -766,11 +776,11 @@ __global__ __launch_bounds__(256) void edge_fwd3_kernel(EdgeFwdArgs A) {
         return;
     }
     const vnf<N> hp = acc * __builtin_amdgcn_rcpf(Z + 1e-8f);    // E:379 epsilon
-    *reinterpret_cast<vnf<N>*>(A.hpre + (int64_t)row * HD + c) = hp;
+    stream_store(reinterpret_cast<vnf<N>*>(A.hpre + (int64_t)row * HD + c), hp);
     if ((c % D) == 0) { A.mstat[(int64_t)row * H + c / D] = m; A.zstat[(int64_t)row * H + c / D] = Z; }
     const vnf<N> act = lrelu_n<N>(hp, A.slope);
     if (!A.is_last) {
-        *reinterpret_cast<vnf<N>*>(A.hout + (int64_t)row * HD + c) = act;     // concat heads (E:452-457)
+        stream_store(reinterpret_cast<vnf<N>*>(A.hout + (int64_t)row * HD + c), act);     // concat heads (E:452-457)
     } else {
         vnf<N> t = act;                              // activate, then average heads (E:440-449)
 #pragma unroll
@@ -1013,7 +1023,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 for (int i = 0; i < N; ++i) nib |= (hp[i] > 0.f ? 1u : 0u) << i;
                 A.hbits[rowc * A.hb_stride + cp] = (uint8_t)nib;
             } else {
-                store_row_n<HD, N, BF>(A.gfull, (int)rowc, cp, g);   // bf16 storage: the gathered g table is 2-byte too
+                if constexpr (BF) store_row_n<HD, N, BF>(A.gfull, (int)rowc, cp, g);   // bf16 storage: the gathered g table is 2-byte too
+                else stream_store(reinterpret_cast<vnf<N>*>(A.gfull + rowc * HD + c), g);
             }
         }
         vnf<N> gpr = vzero<N>();
@@ -1038,7 +1049,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 *reinterpret_cast<uint4*>(A.stash + (uint64_t)(uint32_t)(j0 < e ? j0 : 0) * LPE + cp * 4) = w4;
             } else if constexpr (DBG != 1) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) A.stash[(uint64_t)pend_s[u] * LPE + cp] = pend_w[u];
+                for (int u = 0; u < U; ++u) stream_store(&A.stash[(uint64_t)pend_s[u] * LPE + cp], pend_w[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) pend_s[u] = sl[u];
@@ -1071,11 +1082,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
         if constexpr (DBG != 1 && DBG != 3) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) A.stash[(uint64_t)pend_s[u] * LPE + cp] = pend_w[u];         // the last step's records
+            for (int u = 0; u < U; ++u) stream_store(&A.stash[(uint64_t)pend_s[u] * LPE + cp], pend_w[u]);      // the last step's records
         }
         if (row >= 0) {
             float* dst = slot < 0 ? A.gPR + rowc * HD + c : A.part_acc + (int64_t)slot * HD + c;   // segment partial -> fix kernel
-            *reinterpret_cast<vnf<N>*>(dst) = gpr;
+            stream_store(reinterpret_cast<vnf<N>*>(dst), gpr);
         }
     }
 #pragma unroll
