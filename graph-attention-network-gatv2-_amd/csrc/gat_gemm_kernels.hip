@@ -11,8 +11,8 @@
 // Arithmetic (round 2): the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) runs at 1/16 of
 // the bf16 rate and made every kernel here MFMA-bound at Products size.  The default kernels (*_x3_*) cut each fp32
 // operand EXACTLY into three bf16 pieces and run six bf16 MFMAs per product with fp32 accumulation: error per product
-// < 2^-23, measured error of a K = 100 dot product 6.9e-7 x sum|a||b| against 8.5e-7 for the reference's own fp32 fma
-// chain (tests/test_dense_precision.py).  The fp32-MFMA kernels stay as the A/B (GAT_GEMM_X3=0, GAT_GRADW_X3=0).
+// < 2^-21 worst case, 0.7 x 2^-24 on average (tests/test_split_pieces.py); measured error of a K = 100 dot product
+// 6.9e-7 x sum|a||b| against 8.5e-7 for the reference's own fp32 fma chain (tests/test_dense_precision.py).  The fp32-MFMA kernels stay as the A/B (GAT_GEMM_X3=0, GAT_GRADW_X3=0).
 //
 // Shapes are skinny: M = nodes (millions), K and N <= ~128.  project / grad_x keep the whole B operand resident in
 // LDS for the lifetime of a persistent block and stream A straight from HBM into MFMA fragments.  grad_w reduces
@@ -333,9 +333,12 @@ __global__ __launch_bounds__(256) void rowgemm_pipe_kernel(AS as, BS bs, EP ep, 
 // by it, not by HBM.  An fp32 value is EXACTLY hi + mid + lo with three bf16 pieces of 8 significant bits
 // each (cut by truncation: the remainders x - hi and (x - hi) - mid are exact in fp32), a bf16 x bf16 product is exact
 // in fp32, and the MFMA accumulates in fp32.  Of the nine piece products of a·b the six with (piece index of a) +
-// (piece index of b) <= 2 are kept: the dropped ones sum to < 2^-23 |a·b|, the size of the rounding of one fp32
-// product.  Six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles for K = 16) replace eight 32x32x2_f32 (8 x 64 cycles), and
-// the kernel becomes HBM-bound.  Small terms are accumulated first.
+// (piece index of b) <= 2 are kept: the dropped ones (mid·lo, lo·mid, lo·lo) sum to < 2^-21 |a·b| in the worst case and
+// 0.7 x 2^-24 |a·b| on average — the size of the rounding of one fp32 product (tests/test_split_pieces.py); a K-term
+// dot product comes out closer to the exact one than an fp32 fma chain does (tests/test_dense_precision.py).
+// -DGAT_X3_EIGHT_TERMS adds mid·lo and lo·mid (< 2^-29; +0.2 ms per Products step: not the default).  Six
+// v_mfma_f32_32x32x16_bf16 (6 x 32 cycles for K = 16) replace eight 32x32x2_f32 (8 x 64 cycles), and the kernel
+// becomes HBM-bound.  Small terms are accumulated first.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // two floats -> the packed (x0 | x1 << 16) bf16 pairs of their hi / mid / lo pieces
@@ -425,6 +428,10 @@ __global__ __launch_bounds__(WAVES * 64) void rowgemm_x3_kernel(AS as, BS bs, EP
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const uint4 bh = bp[nt * 32], bm = bp[plane + nt * 32], bl = bp[2 * plane + nt * 32];
+#ifdef GAT_X3_EIGHT_TERMS
+            acc[nt] = mfma_bf16(a.lo, bm, acc[nt]);
+            acc[nt] = mfma_bf16(a.mid, bl, acc[nt]);
+#endif
             acc[nt] = mfma_bf16(a.lo, bh, acc[nt]);
             acc[nt] = mfma_bf16(a.hi, bl, acc[nt]);
             acc[nt] = mfma_bf16(a.mid, bm, acc[nt]);
@@ -600,6 +607,10 @@ __global__ __launch_bounds__(256) void project_splitk_x3_kernel(ASrcRows as, BSr
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const uint4 bh = bp[nt * 32], bm = bp[plane + nt * 32], bl = bp[2 * plane + nt * 32];
+#ifdef GAT_X3_EIGHT_TERMS
+            acc[nt] = mfma_bf16(a.lo, bm, acc[nt]);
+            acc[nt] = mfma_bf16(a.mid, bl, acc[nt]);
+#endif
             acc[nt] = mfma_bf16(a.lo, bh, acc[nt]);
             acc[nt] = mfma_bf16(a.hi, bl, acc[nt]);
             acc[nt] = mfma_bf16(a.mid, bm, acc[nt]);
@@ -971,6 +982,10 @@ __global__ __launch_bounds__(256) void gradw_x3_kernel(const float* __restrict__
         for (int x = 0; x < 2; ++x)
 #pragma unroll
             for (int y = 0; y < NY; ++y) {
+#ifdef GAT_X3_EIGHT_TERMS
+                acc[x][y] = mfma_bf16(a[x][2], b[y][1], acc[x][y]);
+                acc[x][y] = mfma_bf16(a[x][1], b[y][2], acc[x][y]);
+#endif
                 acc[x][y] = mfma_bf16(a[x][2], b[y][0], acc[x][y]);
                 acc[x][y] = mfma_bf16(a[x][0], b[y][2], acc[x][y]);
                 acc[x][y] = mfma_bf16(a[x][1], b[y][1], acc[x][y]);

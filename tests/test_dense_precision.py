@@ -1,6 +1,7 @@
 """The dense kernels (projection, grad_w) run on the bf16 matrix pipe with every fp32 operand cut into three bf16
 pieces (csrc/gat_gemm_kernels.hip: rowgemm_x3_kernel, project_splitk_x3_kernel, gradw_x3_kernel).  The claim is that
-this is an fp32-accurate product — error per product < 2^-23, like one fp32 rounding — and NOT a reduced-precision one.
+this is an fp32-accurate product — error per product < 2^-21 worst case, one fp32 rounding (2^-24) on average:
+tests/test_split_pieces.py — and NOT a reduced-precision one.
 These tests hold the kernels to that, against an fp64 product of the same fp32 inputs, with the yardstick the reference
 itself sets: its per-edge float loop (E:303-316) is a chain of K fused multiply-adds, emulated here in numpy on the same
 data (`_chain_ratio`).  With  ratio = max |got - exact| / sum_k |a_k| |b_k|  over all outputs:
