@@ -10,9 +10,9 @@
 //
 // Arithmetic (round 2): the fp32 matrix instruction (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) runs at 1/16 of
 // the bf16 rate and made every kernel here MFMA-bound at Products size.  The default kernels (*_x3_*) cut each fp32
-// operand EXACTLY into three bf16 pieces and run six bf16 MFMAs per product with fp32 accumulation: error per product
-// < 2^-21 worst case, 0.7 x 2^-24 on average (tests/test_split_pieces.py); measured error of a K = 100 dot product
-// 6.9e-7 x sum|a||b| against 8.5e-7 for the reference's own fp32 fma chain (tests/test_dense_precision.py).  The fp32-MFMA kernels stay as the A/B (GAT_GEMM_X3=0, GAT_GRADW_X3=0).
+// operand EXACTLY into three bf16 pieces (rounded to nearest) and run six bf16 MFMAs per product with fp32 accumulation:
+// error per product < 2^-24 — below the rounding of an fp32 multiply — in the worst case (tests/test_split_pieces.py);
+// a K-term dot product comes out at or below the error of the reference's own fp32 fma chain (tests/test_dense_precision.py).  The fp32-MFMA kernels stay as the A/B (GAT_GEMM_X3=0, GAT_GRADW_X3=0).
 //
 // Shapes are skinny: M = nodes (millions), K and N <= ~128.  project / grad_x keep the whole B operand resident in
 // LDS for the lifetime of a persistent block and stream A straight from HBM into MFMA fragments.  grad_w reduces
@@ -331,25 +331,31 @@ __global__ __launch_bounds__(256) void rowgemm_pipe_kernel(AS as, BS bs, EP ep, 
 // ---- the same product on the bf16 matrix pipe, fp32 operands cut into three bf16 pieces -----------------------------
 // v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate, and at Products size every dense kernel of the step is bound
 // by it, not by HBM.  An fp32 value is EXACTLY hi + mid + lo with three bf16 pieces of 8 significant bits
-// each (cut by truncation: the remainders x - hi and (x - hi) - mid are exact in fp32), a bf16 x bf16 product is exact
-// in fp32, and the MFMA accumulates in fp32.  Of the nine piece products of a·b the six with (piece index of a) +
-// (piece index of b) <= 2 are kept: the dropped ones (mid·lo, lo·mid, lo·lo) sum to < 2^-21 |a·b| in the worst case and
-// 0.7 x 2^-24 |a·b| on average — the size of the rounding of one fp32 product (tests/test_split_pieces.py); a K-term
-// dot product comes out closer to the exact one than an fp32 fma chain does (tests/test_dense_precision.py).
-// -DGAT_X3_EIGHT_TERMS adds mid·lo and lo·mid (< 2^-29; +0.2 ms per Products step: not the default).  Six
+// each, cut by rounding to nearest (the remainders x - hi and (x - hi) - mid are exact in fp32, and the second has at most
+// 8 significant bits), a bf16 x bf16 product is exact in fp32, and the MFMA accumulates in fp32.  Of the nine piece
+// products of a·b the six with (piece index of a) + (piece index of b) <= 2 are kept: the dropped ones (mid·lo, lo·mid,
+// lo·lo) sum to < 2^-24 |a·b| in the worst case, 2^-28 on average — less than the rounding of one fp32 multiply
+// (tests/test_split_pieces.py); what remains is the fp32 accumulation, as in an fma chain.
+// -DGAT_X3_EIGHT_TERMS adds mid·lo and lo·mid (< 2^-33; +0.2 ms per Products step: not the default).  Six
 // v_mfma_f32_32x32x16_bf16 (6 x 32 cycles for K = 16) replace eight 32x32x2_f32 (8 x 64 cycles), and the kernel
-// becomes HBM-bound.  Small terms are accumulated first.
+// becomes HBM-bound.  Small terms are accumulated first.  Non-finite operands (and |x| within half a bf16 ulp of
+// FLT_MAX, which rounds to inf) give NaN: inf - inf in the first remainder.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// two floats -> the packed (x0 | x1 << 16) bf16 pairs of their hi / mid / lo pieces
+// two floats -> the packed (x0 | x1 << 16) bf16 pairs of their hi / mid / lo pieces.  Pieces are cut by ROUNDING to
+// nearest (v_cvt_pk_bf16_f32): hi = bf16(x), mid = bf16(x - hi), lo = (x - hi) - mid; both remainders are exact in fp32 and
+// the last one has <= 8 significant bits, so hi + mid + lo == x exactly, with |mid| <= 2^-9 |x|, |lo| <= 2^-17 |x|.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
-    const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                 // {u1[31:16], u0[31:16]}
-    const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
-    const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    mid = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    const float q0 = r0 - __uint_as_float(v0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
-    lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+    hi = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+    mid = cvt_pk_bf16(r0, r1);
+    const float q0 = r0 - __uint_as_float(mid << 16), q1 = r1 - __uint_as_float(mid & 0xFFFF0000u);
+    lo = cvt_pk_bf16(q0, q1);
 }
 struct Pieces { uint4 hi, mid, lo; };                                // 8 consecutive k of one row / column
 __device__ __forceinline__ Pieces split8(const float4& a, const float4& b) {
