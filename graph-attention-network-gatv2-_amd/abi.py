@@ -55,6 +55,7 @@ COMM_PIPELINE = 2
 (K_PROJECT, K_EDGE_FWD, K_HEAD_FWD, K_HEAD_BWD, K_EDGE_BWD, K_GPL_SUM, K_GRAD_W, K_GRAD_X, K_MISC,
  K_EXCHANGE, K_COUNT) = range(11)
 COMM_ID_BYTES = 128
+PATH_GENERIC_SHAPE, PATH_FAST, PATH_GENERIC_SIZE = 0, 1, 2
 
 _lib: Optional[C.CDLL] = None
 
@@ -146,6 +147,7 @@ def _declare(lib: C.CDLL) -> None:
         "gat_layer_backward_edges": [vp, i32],
         "gat_layer_backward_dense": [vp, i32],
         "gat_layer_exchange": [vp, i32, P(i32)],
+        "gat_layer_path": [vp, i32, P(i32)],
         "gat_table": [vp, C.c_int, i32, P(vp), P(i64), P(i64)],
         "gat_bind_table": [vp, C.c_int, i32, vp, i64],
         "gat_tap": [vp, C.c_int, i32, vp, i64],
@@ -417,6 +419,16 @@ class GatContext:
         need = C.c_int32(0)
         _chk(self.lib.gat_layer_exchange(self._ctx, l, C.byref(need)))
         return bool(need.value)
+
+    def layer_path(self, l: int) -> int:
+        """PATH_FAST / PATH_GENERIC_SHAPE / PATH_GENERIC_SIZE: the edge kernels layer l runs on."""
+        p = C.c_int32(0)
+        _chk(self.lib.gat_layer_path(self._ctx, l, C.byref(p)))
+        return p.value
+
+    def last_message(self) -> str:
+        """gat_last_error(): after a successful call either stale text or a "warning: ..." left by that call."""
+        return self.lib.gat_last_error().decode("utf-8", "replace")
 
     def table(self, which: int, l: int):
         p, n, w = C.c_void_p(), C.c_int64(), C.c_int64()

@@ -106,7 +106,9 @@ struct gat_ctx {
     int32_t* row_ptr = nullptr; int32_t* col_idx = nullptr; int32_t* labels = nullptr;
     int32_t* labels_eff = nullptr;                  // with a training mask: label, or ~label outside the mask (gat_set_train_mask)
     int32_t* labels_eff_buf = nullptr;              // its storage (labels_eff is null while no mask is set)
-    uint8_t* mask_tmp = nullptr;                    // [n_rows] device copy of the mask of the last gat_set_train_mask / gat_eval_mask
+    uint8_t* mask_tmp = nullptr;                    // [n_rows] device copy of the mask of the last gat_eval_mask
+    uint8_t* train_mask = nullptr;                  // [n_rows] device copy of the active training mask (re-applied when the labels change)
+    int64_t n_labels = 0;                           // length the labels were set with
     double* eval_loss = nullptr; int32_t* eval_cnt = nullptr;      // block partials of gat_eval_mask
     float* X0 = nullptr;
     float* Xtab = nullptr;                          // [n_table][in_dim] replicated layer-0 input (gat_set_source_features)
@@ -145,7 +147,7 @@ struct gat_ctx {
     int4* items = nullptr; int4* slot_info = nullptr;
     float* part_acc = nullptr; float* part_mz = nullptr;
     float* ga_partial = nullptr; int32_t ga_blocks = 0;
-    float* gw_scratch = nullptr; std::vector<int64_t> gw_off;       // [L] first float of each layer's grad_w slab region
+    float* gw_scratch = nullptr; int64_t gw_scratch_floats = 0; std::vector<int64_t> gw_off;       // [L] first float of each layer's grad_w slab region
     float* hb_partial = nullptr;
     double* loss_partial = nullptr; int32_t* correct_partial = nullptr;
     float* loss_out = nullptr; int32_t* correct_out = nullptr;
@@ -345,8 +347,14 @@ static int ensure_buffers(gat_ctx* c) {
     for (int l = 0; l < L; ++l) { c->gw_off[(size_t)l] = gw; gw += grad_w_scratch_floats(N, c->layers[l].F, c->layers[l].HD); }
     gw = std::max<int64_t>(gw, 1);
     if (c->Xtab) gw = std::max(gw, grad_w_scratch_floats(T, c->layers[0].F, c->layers[0].HD));
-    for (int l = 0; l < L; ++l) gw = std::max(gw, project_scratch_floats(l == 0 && c->Xtab ? T : N, c->layers[l].F, c->layers[l].HD));   // split-K projection (few rows, long K)
+    // split-K projection (few rows, long K): sized from the exact (rows, part) pairs gat_layer_project launches
+    for (int l = 0; l < L; ++l) {
+        const Layer& y = c->layers[l];
+        if (l == 0 && c->Xtab) gw = std::max({gw, project_scratch_floats(T, y.F, y.HD, kPartLeft), project_scratch_floats(N, y.F, y.HD, kPartRight)});
+        else gw = std::max(gw, project_scratch_floats(N, y.F, y.HD, kPartBoth));
+    }
     GAT_TRY(dalloc(c, &c->gw_scratch, gw));
+    c->gw_scratch_floats = gw;
     const int C = c->cfg.num_classes, DL = c->layers[L - 1].D;
     GAT_TRY(dalloc(c, &c->hb_partial, (int64_t)head_bwd_blocks(N, C, DL) * C * DL));
     GAT_TRY(dalloc(c, &c->loss_partial, head_blocks(N)));
@@ -355,6 +363,15 @@ static int ensure_buffers(gat_ctx* c) {
     GAT_TRY(dalloc(c, &c->correct_out, 1));
     GAT_TRY(dalloc(c, &c->y, N * C));
     c->buffers_ready = true;
+    // The cliff of gatv2_abi.h "Limits": a layer whose SHAPE has wave-per-row kernels but whose gathered table is 4 GiB or
+    // more drops to the generic float-atomic kernels.  Not an error (same results) — but never silent: the call that
+    // completed the context returns 0 with this text in gat_last_error(), and gat_layer_path() reports it per layer.
+    for (int l = 0; l < L; ++l) {
+        const Layer& y = c->layers[l];
+        if (!edge_fast_path(y.H, y.D, T) && edge_fast_path(y.H, y.D, 1))
+            set_error("warning: layer " + std::to_string(l) + ": source table of " + std::to_string(T) + " rows x " + std::to_string(y.HD) +
+                      " floats is >= 4 GiB — this layer runs on the generic float-atomic kernels (several times slower); shard the graph by destination range to stay on the wave-per-row path");
+    }
     return 0;
 }
 
@@ -528,6 +545,14 @@ int gat_set_source_features(gat_ctx* c, const float* x, int64_t n_table, int32_t
 int gat_set_source_features_device(gat_ctx* c, const float* x, int64_t n_table, int32_t in_dim) {
     return set_source_features_common(c, x, n_table, in_dim, hipMemcpyDeviceToDevice);
 }
+int gat_layer_path(gat_ctx* c, int32_t l, int32_t* path) {
+    if (!c || !path) return fail(GAT_E_INVALID, "null argument");
+    if (l < 0 || l >= c->cfg.num_layers) return fail(GAT_E_INVALID, "layer index out of range");
+    if (!c->have_graph) return fail(GAT_E_STATE, "gat_layer_path: set the graph first");
+    const Layer& y = c->layers[l];
+    *path = edge_fast_path(y.H, y.D, c->n_table) ? GAT_PATH_FAST : (edge_fast_path(y.H, y.D, 1) ? GAT_PATH_GENERIC_SIZE : GAT_PATH_GENERIC_SHAPE);
+    return 0;
+}
 int gat_layer_exchange(gat_ctx* c, int32_t l, int32_t* needed) {
     if (!c || !needed) return fail(GAT_E_INVALID, "null argument");
     if (l < 0 || l >= c->cfg.num_layers) return fail(GAT_E_INVALID, "layer index out of range");
@@ -541,18 +566,22 @@ static int set_labels_common(gat_ctx* c, const int32_t* labels, int64_t n_rows, 
     if (kind == hipMemcpyHostToDevice)
         for (int64_t i = 0; i < n_rows; ++i)
             if (labels[i] < 0 || labels[i] >= c->cfg.num_classes) return fail(GAT_E_INVALID, "label outside [0, num_classes)");
+    if (c->labels && n_rows != c->n_labels) return fail(GAT_E_INVALID, "gat_set_labels: length differs from the labels set before");
     if (!c->labels) GAT_TRY(dalloc(c, &c->labels, n_rows));
+    c->n_labels = n_rows;
     GAT_HIP(hipMemcpyAsync(c->labels, labels, n_rows * sizeof(int32_t), kind, c->stream));
+    // an active training mask applies to the NEW labels too: labels_eff holds masked copies, not a view
+    if (c->labels_eff != nullptr) GAT_TRY(launch_apply_mask(c->labels, c->train_mask, c->labels_eff_buf, n_rows, c->stream));
     GAT_HIP(hipStreamSynchronize(c->stream));
     c->have_labels = true;
     return ensure_buffers(c);
 }
 // ---- train / validation masks (the reference trains and evaluates on ALL nodes, README R:134: "later") ----------
-static int upload_mask(gat_ctx* c, const uint8_t* mask, int64_t n_rows) {
+static int upload_mask(gat_ctx* c, const uint8_t* mask, int64_t n_rows, uint8_t** dst) {
     if (!c->have_labels) return fail(GAT_E_STATE, "set the labels first");
-    if (n_rows != c->n_rows && c->have_graph) return fail(GAT_E_INVALID, "mask length differs from the node count");
-    if (!c->mask_tmp) GAT_TRY(dalloc(c, &c->mask_tmp, n_rows));
-    GAT_HIP(hipMemcpyAsync(c->mask_tmp, mask, (size_t)n_rows, hipMemcpyHostToDevice, c->stream));
+    if (n_rows != c->n_labels || (c->have_graph && n_rows != c->n_rows)) return fail(GAT_E_INVALID, "mask length differs from the node count");
+    if (!*dst) GAT_TRY(dalloc(c, dst, n_rows));
+    GAT_HIP(hipMemcpyAsync(*dst, mask, (size_t)n_rows, hipMemcpyHostToDevice, c->stream));
     return 0;
 }
 int gat_set_train_mask(gat_ctx* c, const uint8_t* mask, int64_t n_rows) {
@@ -562,9 +591,9 @@ int gat_set_train_mask(gat_ctx* c, const uint8_t* mask, int64_t n_rows) {
         graph_drop_fwd(c);
         return 0;
     }
-    GAT_TRY(upload_mask(c, mask, n_rows));
+    GAT_TRY(upload_mask(c, mask, n_rows, &c->train_mask));
     if (!c->labels_eff_buf) GAT_TRY(dalloc(c, &c->labels_eff_buf, n_rows));      // one buffer, reused by later calls
-    GAT_TRY(launch_apply_mask(c->labels, c->mask_tmp, c->labels_eff_buf, n_rows, c->stream));
+    GAT_TRY(launch_apply_mask(c->labels, c->train_mask, c->labels_eff_buf, n_rows, c->stream));
     GAT_HIP(hipStreamSynchronize(c->stream));
     c->labels_eff = c->labels_eff_buf;
     graph_drop_fwd(c);                              // a captured step holds the old label pointer
@@ -574,7 +603,7 @@ int gat_eval_mask(gat_ctx* c, const uint8_t* mask, int64_t n_rows, double* loss_
     GAT_TRY(check_layer(c, 0));
     if (!mask) return fail(GAT_E_INVALID, "gat_eval_mask: null mask");
     if (!c->y_valid) GAT_TRY(gat_head_forward(c, nullptr, nullptr));     // after a fused head step: y = f(H_L, Wo), both still there
-    GAT_TRY(upload_mask(c, mask, n_rows));
+    GAT_TRY(upload_mask(c, mask, n_rows, &c->mask_tmp));
     const int blocks = 256;
     if (!c->eval_loss) { GAT_TRY(dalloc(c, &c->eval_loss, blocks)); GAT_TRY(dalloc(c, &c->eval_cnt, 2 * blocks)); }
     GAT_TRY(launch_eval_mask(c->y, c->labels, c->mask_tmp, n_rows, c->cfg.num_classes, c->eval_loss, c->eval_cnt, blocks, c->stream));
@@ -687,11 +716,11 @@ int gat_layer_project(gat_ctx* c, int32_t l) {
     Layer& y = c->layers[l];
     Scope t(c, GAT_K_PROJECT);
     if (l == 0 && c->Xtab) {      // replicated input: whole PL table from the table rows, PR from the shard's rows
-        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->gw_scratch, c->stream));
-        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->gw_scratch, c->stream);
+        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream));
+        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream);
     }
     float* own_rows = reinterpret_cast<float*>(reinterpret_cast<char*>(y.PL) + c->table_row0 * y.HD * st_bytes(c));
-    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->stream);
+    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream);
 }
 
 int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
@@ -851,7 +880,7 @@ static int forward_exchange_pipelined(gat_ctx* c, int l) {
         if (r0 >= max_rows) break;
         if (r1 > r0)
             GAT_TRY(launch_project(Xin_of(c, l) + r0 * y.F, W_of(c, l), reinterpret_cast<float*>(own_rows + r0 * y.HD * st_bytes(c)),
-                                   y.PR + r0 * y.HD, r1 - r0, y.F, y.HD, kPartBoth, bf16(c), nullptr, c->stream));
+                                   y.PR + r0 * y.HD, r1 - r0, y.F, y.HD, kPartBoth, bf16(c), nullptr, 0, c->stream));
         GAT_HIP(hipEventRecord(c->comm_events[k], c->stream));
         GAT_HIP(hipStreamWaitEvent(c->comm_stream, c->comm_events[k], 0));
         GAT_TRY(c->comm->all_gather_part(y.PL, pl_slice(c, y), r0 * rowf, (r1s - r0) * rowf, c->comm_stream));
@@ -862,7 +891,10 @@ static int forward_exchange_pipelined(gat_ctx* c, int l) {
 }
 static int forward_phases(gat_ctx* c) {
     for (int l = 0; l < c->cfg.num_layers; ++l) {
-        if (c->comm && needs_exchange(c, l) && c->comm_chunks > 1) {
+        // the chunked projection runs the streaming kernel; a layer whose one-launch projection takes the split-K kernel
+        // (few rows, F > 128: another summation order) keeps the plain exchange, so that K chunks stay bitwise K = 1
+        if (c->comm && needs_exchange(c, l) && c->comm_chunks > 1 &&
+            project_scratch_floats(c->n_rows, c->layers[l].F, c->layers[l].HD, kPartBoth) == 0) {
             GAT_TRY(check_layer(c, l));
             GAT_TRY(forward_exchange_pipelined(c, l));
             GAT_TRY(gat_layer_forward_edges(c, l));
@@ -1311,7 +1343,7 @@ int gat_op_layer_forward(const int32_t* d_row_ptr, const int32_t* d_col_idx, con
     float *PL, *PR, *alpha, *ms, *zs;
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
     GAT_TRY(t.get(&ms, n * h)); GAT_TRY(t.get(&zs, n * h));
-    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, nullptr, s));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, nullptr, 0, s));
     EdgeFwdArgs a{};
     a.row_ptr = d_row_ptr; a.col_idx = d_col_idx; a.PL = PL; a.PR = PR; a.a = d_a; a.alpha = alpha;
     a.mstat = ms; a.zstat = zs;
@@ -1345,7 +1377,7 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
     GAT_TRY(t.get(&PL, n * HD)); GAT_TRY(t.get(&PR, n * HD)); GAT_TRY(t.get(&alpha, e * h));
     GAT_TRY(t.get(&gPL, n * HD)); GAT_TRY(t.get(&gPR, n * HD)); GAT_TRY(t.get(&gap, (int64_t)blocks * HD));
     GAT_TRY(t.get(&scr, grad_w_scratch_floats(n, f, HD)));
-    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, nullptr, s));
+    GAT_TRY(launch_project(d_x, d_w, PL, PR, n, f, HD, kPartBoth, false, nullptr, 0, s));
     GAT_TRY(launch_transpose_he_to_eh(d_attn_coeff, alpha, e, h, s));
     GAT_TRY(t.worklist(d_row_ptr, n, HD, h, s));
     // softmax stats of this layer (the fast-path backward recomputes alpha from them): one

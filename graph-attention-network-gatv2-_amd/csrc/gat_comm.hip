@@ -170,7 +170,9 @@ struct RcclComm final : Comm {
         GAT_TRY(launch_pack_bf16(table, out, (int64_t)world * slice, s));
         GAT_NCCL(api, api->GroupStart());
         for (int q = 0; q < world; ++q) {
-            if (q == rank) continue;
+            // world 1: a self send/recv pair through the staging buffers, so that the point-to-point symbols, the group and
+            // the launch are exercised on a one-GPU box too (the arrival is not summed: q == rank keeps its fp32 partial)
+            if (q == rank && world > 1) continue;
             GAT_NCCL(api, api->Send(out + (int64_t)q * slice, (size_t)slice * 2, kNcclInt8, q, comm, s));
             GAT_NCCL(api, api->Recv(in + (int64_t)q * slice, (size_t)slice * 2, kNcclInt8, q, comm, s));
         }

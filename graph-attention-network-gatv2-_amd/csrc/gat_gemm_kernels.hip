@@ -1065,18 +1065,21 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD) {
-    return project_wants_splitk(n_rows, 2 * HD, F) ? (int64_t)((F + 127) / 128) * n_rows * 2 * HD : 0;
+int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD, int32_t part) {
+    const int32_t N = part == kPartBoth ? 2 * HD : HD;
+    return project_wants_splitk(n_rows, N, F) ? (int64_t)((F + 127) / 128) * n_rows * N : 0;
 }
 
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows, int32_t F,
-                   int32_t HD, int32_t part, bool pl_bf16, float* scratch, hipStream_t s) {
+                   int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s) {
     const int32_t j0 = part == kPartRight ? HD : 0;
     ASrcRows as{X, F};
     BSrcProject bs{W, F, HD, j0};
     const bool vec4 = (F % 4 == 0) && aligned16(X);
     const int32_t N = part == kPartBoth ? 2 * HD : HD;
-    if (scratch != nullptr && n_rows > 0 && project_wants_splitk(n_rows, N, F)) {
+    // split-K only when the caller's scratch holds this launch's slabs (the capacity is the caller's to state: a buffer
+    // sized for another (rows, part) pair must not be overrun) — otherwise the streaming kernel, same results up to summation order
+    if (scratch != nullptr && n_rows > 0 && project_wants_splitk(n_rows, N, F) && scratch_floats >= (int64_t)((F + 127) / 128) * n_rows * N) {
         const int ksplit = (F + 127) / 128;
         const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)ksplit);
         static const bool x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return !(e && e[0] == '0'); }();       // A/B: 0 = fp32 MFMA

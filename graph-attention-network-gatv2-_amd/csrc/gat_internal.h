@@ -213,11 +213,12 @@ int launch_transpose_nh_to_hn(const float* src_nh, float* dst_hn, int64_t N, int
 // different row sets when the layer input is replicated on every shard (gat_set_source_features).
 enum : int32_t { kPartBoth = 0, kPartLeft = 1, kPartRight = 2 };
 // pl_bf16: PL_rows points at bf16 rows ([.][HD] of 2 bytes) — cfg.storage_dtype
-// scratch: project_scratch_floats(n_rows, F, HD) floats (0 = never needed), or null (then always the streaming kernel);
-// few rows with a long K (Cora / Pubmed shapes) take a split-K path through it
-int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);
+// scratch / scratch_floats: a buffer of at least project_scratch_floats(n_rows, F, HD, part) floats (0 = this launch never
+// needs one), or null; few rows with a long K (Cora / Pubmed shapes) take a split-K path through it.  A scratch smaller than
+// this launch needs (or null) selects the streaming kernel — never an overrun.
+int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD, int32_t part);
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows,
-                   int32_t F, int32_t HD, int32_t part, bool pl_bf16, float* scratch, hipStream_t s);
+                   int32_t F, int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s);
 // gradW[j][0:F] += sum_n gPL[n][j] X[n][:],  gradW[j][F:2F] += sum_n gPR[n][j] X[n][:]
 // scratch: at least grad_w_scratch_floats(n_rows, F, HD) floats.
 int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAT_ABI_VERSION 3
+#define GAT_ABI_VERSION 4
 
 enum {
     GAT_OK = 0,
@@ -85,6 +85,20 @@ int gat_mem_info(size_t* free_bytes, size_t* total_bytes);   /* cudaMemGetInfo, 
  * (no BASELINE config is that large per GPU; bf16 storage is refused there). */
 int gat_set_graph(gat_ctx* ctx, const int32_t* row_ptr, const int32_t* col_idx, int64_t n_rows,
                   int64_t n_edges, int64_t n_table, int64_t table_row0);
+/* Which edge kernels layer `layer` runs on (known once the graph is set).  The size cliff above is never silent: the
+ * gat_set_* call that completes the context (graph + features + labels) still returns 0, but leaves a text starting with
+ * "warning:" in gat_last_error() when a layer is GAT_PATH_GENERIC_SIZE. */
+enum {
+    GAT_PATH_GENERIC_SHAPE = 0,   /* (H, D) outside the wave-per-row templates (H*D not in {8,16,32,64} or D not a power of two) */
+    GAT_PATH_FAST = 1,            /* wave-per-row / group-per-row kernels, no atomics */
+    GAT_PATH_GENERIC_SIZE = 2     /* the shape has fast kernels, but the gathered table is >= 4 GiB */
+};
+int gat_layer_path(gat_ctx* ctx, int32_t layer, int32_t* path);
+/* Non-finite inputs: the reference's plain fp32 loops (E:303-316) turn a +-inf feature into +-inf or NaN sums and a
+ * non-finite loss.  Here the dense products cut every fp32 operand into three bf16 pieces (x - bf16(x) is inf - inf for an
+ * infinite x), so a non-finite — or within half a bf16 ulp of FLT_MAX — feature or weight yields NaN where the reference may
+ * yield +-inf: the loss is non-finite in both, the kind of non-finite value may differ.  Nothing hangs or faults
+ * (tests/test_nonfinite.py). */
 int gat_set_features(gat_ctx* ctx, const float* x, int64_t n_rows, int32_t in_dim);   /* [n_rows][F0] */
 int gat_set_labels(gat_ctx* ctx, const int32_t* labels, int64_t n_rows);
 /* Train / validation / test splits — beyond the reference, which trains and evaluates on ALL nodes (E:514-537,

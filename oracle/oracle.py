@@ -251,10 +251,11 @@ def step(cfg: Config, row_ptr, col_idx, labels, X0, W, a, Wo, *, flat_lrelu_inde
     return r
 
 
-def presum_signs(cfg: Config, row_ptr, col_idx, X0, W, ref: "StepResult"):
+def presum_signs(cfg: Config, row_ptr, col_idx, X0, W, ref: "StepResult", values: bool = False):
     """Per layer the sign decisions (s > 0) of the literal restatement, in both float orders the reference
-    uses: -> (pos_lr[l], pos_il[l]) bool arrays [E][H][D]; see orc_presum.  Test infrastructure for the
-    LeakyReLU-kink bookkeeping of tests/parity.py."""
+    uses: -> (pos_lr[l], pos_il[l]) bool arrays [E][H][D]; see orc_presum.  values=True: the float32 pre-activations
+    s themselves instead of their signs (the tests bound |s| where two paths decide differently).  Test
+    infrastructure for the LeakyReLU-kink bookkeeping of tests/parity.py."""
     Lb = lib()
     E = len(col_idx)
     src = np.ascontiguousarray(col_idx, np.int32)
@@ -267,9 +268,9 @@ def presum_signs(cfg: Config, row_ptr, col_idx, X0, W, ref: "StepResult"):
         Wl = W[cfg.w_offsets[l]:cfg.w_offsets[l + 1]]
         s = np.empty(E * H * D, np.float32)
         Lb.orc_presum(Xl, src, dst, Wl, s, F, D, H, E, 0)
-        out_lr.append((s > 0).reshape(E, H, D))
+        out_lr.append(s.reshape(E, H, D).copy() if values else (s > 0).reshape(E, H, D))
         Lb.orc_presum(Xl, src, dst, Wl, s, F, D, H, E, 1)
-        out_il.append((s > 0).reshape(E, H, D))
+        out_il.append(s.reshape(E, H, D).copy() if values else (s > 0).reshape(E, H, D))
     return out_lr, out_il
 
 

@@ -28,6 +28,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-4        # forward tensors and loss (north_star)
 GTOL = 1e-4       # gradients, relative to the tensor's max-abs
 MAX_FLIPS = 64    # more than this in a small test means something other than round-off is going on
+KINK_MARGIN = 1e-5  # a decision may differ between two paths only where the oracle's own pre-activation is within this
+                    # fraction of its tensor's max-abs of zero (fp32 round-off of a sum of ~F terms): a flip at a LARGE |s|
+                    # is a wrong decision, not a kink, and must fail even if it is one of few
 
 _LOG = {}
 _CURRENT = [os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]]      # subprocess snippets inherit the name
@@ -89,20 +92,21 @@ def check_abs(name, got, want, tol=TOL):
 class Flips:
     """Sign decisions of both sides and where they differ."""
 
-    def __init__(self, cfg, gpu_s, gpu_h, orc_lr, orc_il, orc_h):
+    def __init__(self, cfg, gpu_s, gpu_h, orc_lr, orc_il, orc_h, margin=0.0):
         self.cfg = cfg
         self.gpu_s, self.gpu_h = gpu_s, gpu_h
         self.orc_lr, self.orc_il, self.orc_h = orc_lr, orc_il, orc_h
         self.n_s_params = [int((g != o).sum()) for g, o in zip(gpu_s, orc_lr)]
         self.n_s_gx = [int((g != o).sum()) for g, o in zip(gpu_s, orc_il)]
         self.n_h = [int((g != o).sum()) for g, o in zip(gpu_h, orc_h)]
+        self.margin = float(margin)      # max over differing decisions of |oracle pre-activation| / max-abs of its tensor
 
     @property
     def total(self):
         return sum(self.n_s_params) + sum(self.n_s_gx) + sum(self.n_h)
 
     def summary(self):
-        return {"s_params": self.n_s_params, "s_gx": self.n_s_gx, "h_pre": self.n_h}
+        return {"s_params": self.n_s_params, "s_gx": self.n_s_gx, "h_pre": self.n_h, "kink_margin": self.margin}
 
 
 def find_flips(orc, cfg, row_ptr, col_idx, x, W, ref, ctx, A, cache=None):
@@ -118,11 +122,22 @@ def find_flips(orc, cfg, row_ptr, col_idx, x, W, ref, ctx, A, cache=None):
         gpu_s.append((s > 0).reshape(len(src), H, D))
         gpu_h.append(ctx.tap(A.TAP_HPRE, l) > 0)
     cache = {} if cache is None else cache
-    if "orc_signs" not in cache:
-        cache["orc_signs"] = orc.presum_signs(cfg, row_ptr, col_idx, x, W, ref)
+    if "orc_vals" not in cache:
+        cache["orc_vals"] = orc.presum_signs(cfg, row_ptr, col_idx, x, W, ref, values=True)
+        cache["orc_signs"] = tuple([v > 0 for v in vs] for vs in cache["orc_vals"])
     orc_lr, orc_il = cache["orc_signs"]
+    val_lr, val_il = cache["orc_vals"]
     orc_h = [ref.taps["hpre"][l] > 0 for l in range(cfg.L)]
-    return Flips(cfg, gpu_s, gpu_h, orc_lr, orc_il, orc_h)
+    # how far from zero the ORACLE's pre-activation is wherever the two paths decide differently, relative to the
+    # tensor's scale: round-off kinks sit at ~1e-7; anything above KINK_MARGIN is a wrong decision
+    margin = 0.0
+    for l in range(cfg.L):
+        for gpu, want, val in ((gpu_s[l], orc_lr[l], val_lr[l]), (gpu_s[l], orc_il[l], val_il[l]),
+                               (gpu_h[l], orc_h[l], np.asarray(ref.taps["hpre"][l]).reshape(gpu_h[l].shape))):
+            diff = gpu != want
+            if diff.any():
+                margin = max(margin, float(np.abs(val[diff]).max() / max(np.abs(val).max(), 1e-30)))
+    return Flips(cfg, gpu_s, gpu_h, orc_lr, orc_il, orc_h, margin)
 
 
 def expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, max_flips=MAX_FLIPS, cache=None):
@@ -132,6 +147,8 @@ def expected_gradients(cfg, row_ptr, col_idx, labels, x, W, a, Wo, ref, flips, m
                gx=list(ref.taps["gx"]), gradW=ref.gradW, grada=ref.grada, gradWo=ref.gradWo)
     record("kink_flips", flips.total, max_flips, **flips.summary())
     assert flips.total <= max_flips, ("too many LeakyReLU sign differences for round-off", flips.summary())
+    record("kink_margin", flips.margin, KINK_MARGIN)
+    assert flips.margin <= KINK_MARGIN, ("a LeakyReLU decision differs where the oracle's pre-activation is far from 0", flips.summary())
     if flips.total == 0:
         return exp
     import ref64

@@ -82,9 +82,19 @@ def test_config3_arxiv_shape_full_three_layers(pkg, orc):
     _literal_full_check(pkg, orc, "arxiv", (8, 8, 8), (8, 8, 8), mt=True)
 
 
+_PRODUCTS = {}
+
+
+def _products(pkg):
+    """The Products-shape dataset from the HOST generator (14.8 s), shared by the full-size tests of this module."""
+    if "ds" not in _PRODUCTS:
+        _PRODUCTS["ds"] = pkg.synth.make_dataset("products")
+    return _PRODUCTS["ds"]
+
+
 def test_config4_products_shape_full_vs_restructured_cpu(pkg, orc):
     A = pkg.abi
-    ds = pkg.synth.make_dataset("products")
+    ds = _products(pkg)
     n, e = ds["n"], ds["e"]
     heads, outdims = [8, 8], [8, 8]
     cfg = orc.Config(heads, outdims, ds["f"], ds["c"])
@@ -113,3 +123,37 @@ def test_config4_products_shape_full_vs_restructured_cpu(pkg, orc):
     check_rel("gradWo", got[2], gWo)
     check_rel("grada", got[1], ga)
     check_rel("gradW", got[0], gW)
+
+
+def test_config5_kernels_at_products_size_bf16_vs_restructured_cpu(pkg, orc):
+    """The kernels BASELINE config 5 selects (heads 4,4 / outdims 8,8, bf16 storage: H*D = 32 message rows, no record
+    path) at a size where the size-selected variants are in play (61.9 M edges: 256-edge hub segments, chunked source
+    lists, group-per-row kernels), checked NUMERICALLY: loss and all three parameter gradients against the restructured
+    CPU checker in fp32 storage with double accumulators, at the bf16 bar of SURVEY 8c (1e-2).  The checker uses the HIP
+    path's own LeakyReLU' decisions (taken on bf16-rounded PL rows, so ~1e-3 of them differ from the fp32 ones — reported,
+    not bounded: that rounding IS the storage mode); what is compared is everything else."""
+    A = pkg.abi
+    ds = _products(pkg)
+    n, e = ds["n"], ds["e"]
+    heads, outdims = [4, 4], [8, 8]
+    cfg = orc.Config(heads, outdims, ds["f"], ds["c"])
+    W, a, Wo = orc.xavier_params(cfg, 42)
+    with pkg.GatContext(heads, outdims, ds["f"], ds["c"], dtype="bf16") as ctx:
+        ctx.set_graph(ds["row_ptr"], ds["col_idx"]); ctx.set_features(ds["x"]); ctx.set_labels(ds["labels"])
+        ctx.params_set(A.PARAM_W, W); ctx.params_set(A.PARAM_A, a); ctx.params_set(A.PARAM_WO, Wo)
+        ctx.zero_grad()
+        loss, correct = ctx.step()
+        got = [ctx.grads_get(g) for g in (A.PARAM_W, A.PARAM_A, A.PARAM_WO)]
+        decisions = parity.context_decisions(ctx, A, cfg, ds["row_ptr"], ds["col_idx"])
+    loss_ref, correct_ref, gW, ga, gWo, (cnt, mx) = orc.step_restructured(
+        cfg, ds["row_ptr"], ds["col_idx"], ds["labels"], ds["x"], W, a, Wo, acc64=True, decisions=decisions)
+    parity.record("decisions that differ from the fp32 checker's (bf16 rounding of PL)", int(cnt.sum()), float(e * 32 * 2),
+                  s=[int(v) for v in cnt[:, 0]], h_pre=[int(v) for v in cnt[:, 1]], max_abs_value_at_a_flip=float(mx.max()))
+    assert cnt.sum() <= 2e-2 * e * 32 * 2
+    BF = 1e-2
+    check_abs("loss/N (bf16 storage)", loss / n, loss_ref / n, BF)
+    parity.record("n_correct difference (bf16 storage)", abs(correct - correct_ref), 2e-3 * n)
+    assert abs(correct - correct_ref) <= 2e-3 * n
+    check_rel("gradWo (bf16 storage)", got[2], gWo, BF)
+    check_rel("grada (bf16 storage)", got[1], ga, BF)
+    check_rel("gradW (bf16 storage)", got[0], gW, BF)

@@ -363,7 +363,12 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
 @pytest.mark.parametrize("env", [{"GAT_PACKED": "0", "GAT_BWD_STASH": "0"}, {"GAT_CPL": "2", "GAT_BWD_STASH": "0"},
                                  {"GAT_BWD_STASH": "0"}, {"GAT_BWD_ATOMICS": "1"},
                                  {"GAT_FWD_WAVES": "4", "GAT_GPL_WAVES": "1", "GAT_SEG_EDGES": "64"},
-                                 {"GAT_GPL_HEAVY": "64"}])
+                                 {"GAT_GPL_HEAVY": "64"},
+                                 # the headline's last-layer variant (64-B gH / decision-byte records rebuilt by the pull pass): size-selected
+                                 # on the Products shape only, so small tests force it — with both pull kernels, chunked heavy sources,
+                                 # split rows and the wave-per-row backward
+                                 {"GAT_PULL_LAST": "1"}, {"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"},
+                                 {"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "0", "GAT_GPL_HEAVY": "16"}, {"GAT_PULL_LAST": "1", "GAT_ROWGROUP": "0"}])
 def test_ab_switches_stay_correct(pkg, orc, env):
     """The A/B switches of DESIGN §7 select other kernels / launch shapes for the SAME math: each must still
     match the oracle (they are read once per process, hence a subprocess)."""
