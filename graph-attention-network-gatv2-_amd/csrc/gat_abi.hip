@@ -301,7 +301,8 @@ static int ensure_buffers(gat_ctx* c) {
     const char* force = getenv("GAT_BWD_ATOMICS");
     if ((msg_hd > 0 || stash_words > 0) && E > 0 && !(force && force[0] == '1')) {
         float* m = nullptr;
-        if (hipMalloc((void**)&m, std::max<size_t>((size_t)E * msg_hd * (size_t)st_bytes(c), (size_t)(E + 1) * stash_words * sizeof(uint32_t))) == hipSuccess) {
+        // E + 1 rows / records: the last one takes the stores of the group-per-row kernels' padded lanes
+        if (hipMalloc((void**)&m, std::max<size_t>((size_t)(E + 1) * msg_hd * (size_t)st_bytes(c), (size_t)(E + 1) * stash_words * sizeof(uint32_t))) == hipSuccess) {
             c->owned.push_back(m);
             if (msg_hd > 0) { c->msg = m; c->msg_hd = msg_hd; }
             if (stash_words > 0) {                  // records and message rows are never live at the same time: one buffer

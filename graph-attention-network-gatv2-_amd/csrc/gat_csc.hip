@@ -271,6 +271,79 @@ __global__ __launch_bounds__(256) void gpl_sum_group_kernel(const int32_t* __res
     if (s < n_table && !heavy) reinterpret_cast<float4*>(gPL)[s * LPR + q] = acc;
 }
 
+// bf16 message rows, group per source (see gpl_sum_group_kernel): HD/8 lanes own one source's list (a 64-byte row at
+// H*D = 32 is FOUR lanes: one wave per source left 15 of its 16 row slots idle on the ~25-slot lists of BASELINE config 5
+// and paid a 4-level cross-lane reduction per source).  Consecutive sources' lists are contiguous in slot order, so a wave's
+// 64/(HD/8) groups together stream one contiguous region.  Lists beyond kGroupMax go to the whole wave afterwards.
+template <int HD>
+__global__ __launch_bounds__(256) void gpl_sum_bf16_group_kernel(const int32_t* __restrict__ src_ptr,
+                                                                 const float* __restrict__ msg, float* __restrict__ gPL,
+                                                                 int64_t n_table, int32_t kHeavySlots) {
+    constexpr int LPR = HD / 8, RPI = 64 / LPR, U = 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane % LPR, r = lane / LPR;
+    const int64_t s = ((int64_t)blockIdx.x * 4 + wave) * RPI + r;
+    int b = 0, e = 0;
+    if (s < n_table) { b = src_ptr[s]; e = src_ptr[s + 1]; }
+    const bool heavy = (e - b) > kHeavySlots;          // handled by gpl_chunk_kernel + gpl_heavy_fix_kernel
+    const bool big = !heavy && (e - b) > kGroupMax;
+    const uint4* m8 = reinterpret_cast<const uint4*>(msg);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    auto add = [&](float (&a8)[8], const uint4& v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a8[2 * k] += __builtin_bit_cast(float, w[k] << 16);
+            a8[2 * k + 1] += __builtin_bit_cast(float, w[k] & 0xFFFF0000u);
+        }
+    };
+    if (!big && !heavy) {
+        for (int i0 = b; i0 < e; i0 += U) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                v[u] = (i0 + u < e) ? m8[(int64_t)(i0 + u) * LPR + q] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) add(acc, v[u]);
+        }
+    }
+    uint64_t todo = __ballot(big && q == 0);
+    while (todo) {                                     // wave-uniform: every lane sees the same mask
+        const int g = (__ffsll((unsigned long long)todo) - 1) / LPR;
+        todo &= todo - 1;
+        const int bg = __shfl(b, g * LPR), eg = __shfl(e, g * LPR);
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = 0.f;
+        for (int i0 = bg; i0 < eg; i0 += RPI * U) {
+            uint4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * RPI + r;
+                v[u] = (i < eg) ? m8[(int64_t)i * LPR + q] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) add(t, v[u]);
+        }
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] += __shfl_xor(t[k], off);
+        if (r == g) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = t[k];
+        }
+    }
+    if (s < n_table && !heavy) {
+        float4* out = reinterpret_cast<float4*>(gPL + s * HD + q * 8);
+        out[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        out[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Stash path (edge_bwd2_kernel<..., STASH>): the destination-major backward leaves a record of HD/N words per edge
 // in its source-major slot — per head, alpha in the even lane's word and grad_attn_score in the odd lane's, each
@@ -700,6 +773,21 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
     // (6.15 vs 6.31 ms per step on one box)
     static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
     if (msg_bf16) {
+        // group per source unless GAT_GPL_BF16_GROUP=0 (A/B): 10 M / 250 M shape, H*D = 32
+        static const bool bgroup = [] { const char* e = getenv("GAT_GPL_BF16_GROUP"); return !(e && e[0] == '0'); }();
+        if (bgroup) {
+            const int rpi = 64 / (HD / 8);
+            const dim3 ggrid((unsigned)((n_table + 4 * rpi - 1) / (4 * rpi)));
+            switch (HD) {
+                case 64: hipLaunchKernelGGL(gpl_sum_bf16_group_kernel<64>, ggrid, dim3(256), 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+                case 32: hipLaunchKernelGGL(gpl_sum_bf16_group_kernel<32>, ggrid, dim3(256), 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+                case 16: hipLaunchKernelGGL(gpl_sum_bf16_group_kernel<16>, ggrid, dim3(256), 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+                case 8: hipLaunchKernelGGL(gpl_sum_bf16_group_kernel<8>, ggrid, dim3(256), 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;
+                default: return fail(GAT_E_UNSUPPORTED, "gpl_sum: H*D outside the fast path");
+            }
+            GAT_HIP(hipGetLastError());
+            return 0;
+        }
         const dim3 grid((unsigned)((n_table + wpb - 1) / wpb)), block(64 * wpb);
         switch (HD) {
             case 64: hipLaunchKernelGGL(gpl_sum_bf16_kernel<64>, grid, block, 0, s, src_ptr, msg, gPL, n_table, heavy_slots(n_slots)); break;

@@ -960,11 +960,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
 // Group-per-row backward with per-edge records (see edge_fwd3_kernel and the STASH note at bwd2_chunk): persistent
 // waves take quads of G work items (static round-robin over the length-sorted list: every wave gets the same mix).
-template <int HD, int D, int N, int DBG = 0, bool BF = false>
+// MSG = true: the same walk for the layers WITHOUT a record path (bf16 storage at H*D < 64: BASELINE config 5; GAT_BWD_STASH=0):
+// an edge leaves its H*D-element message row g*alpha + ge*a*LReLU' in its source-major slot (summed by launch_gpl_sum) instead
+// of a record, nothing is written for the pull pass (no gfull / decision bytes), any D/N lanes per head.
+template <int HD, int D, int N, int DBG = 0, bool BF = false, bool MSG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void edge_bwd3_kernel(EdgeBwdArgs A) {
     constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
     constexpr int U = 4;
-    static_assert(DL == 2 && LPE >= U, "two lanes per head (one carries alpha, the other ge)");
+    static_assert((MSG || DL == 2) && LPE >= U, "records: two lanes per head (one carries alpha, the other ge)");
     __shared__ float red[4][HD];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const float dot = group_sum<DL>(hsum<N>(g * hp));
         const float m2 = A.mstat[rowc * H + c / D];
         const float inv = __builtin_amdgcn_rcpf(A.zstat[rowc * H + c / D] + 1e-8f);
-        if (row >= 0 && (slot < 0 || b == A.row_ptr[rowc])) {    // one writer per row: whole rows, or a split row's first segment
+        if (!MSG && row >= 0 && (slot < 0 || b == A.row_ptr[rowc])) {    // one writer per row: whole rows, or a split row's first segment
             if (A.hbits != nullptr) {                                // last layer: the decisions only (g = gh * LReLU'(h_pre) / H is rebuilt by the pull pass)
                 uint32_t nib = 0;
 #pragma unroll
@@ -1036,14 +1039,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         // two steps ahead; only then the wait for the gathers, with the stores and index loads still in flight.
         int src[U];
         uint32_t sl[U], pend_s[U], pend_w[U];
+        [[maybe_unused]] vnf<N> pend_m[U];
         spread(0, srcv, posv, src, sl);
 #pragma unroll
-        for (int u = 0; u < U; ++u) { pend_w[u] = 0u; pend_s[u] = A.stash_spare; }
+        for (int u = 0; u < U; ++u) { pend_w[u] = 0u; pend_s[u] = A.stash_spare; if constexpr (MSG) pend_m[u] = vzero<N>(); }
         for (int st = 0; st < nst; ++st) {
             vnf<N> v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) v[u] = gather_row_n<HD, N, BF>(A.PL, src[u], cp);
-            if constexpr (DBG == 3) {                // timing experiment: the step's bytes as ONE 16-B-per-lane store, CSR order
+            if constexpr (MSG) {                     // the previous step's message rows (spare row E for padded lanes)
+#pragma unroll
+                for (int u = 0; u < U; ++u) store_row_n<HD, N, BF>(A.msg, (int)pend_s[u], cp, pend_m[u]);
+            } else if constexpr (DBG == 3) {                // timing experiment: the step's bytes as ONE 16-B-per-lane store, CSR order
                 const int j0 = b + (st > 0 ? st - 1 : 0) * U;
                 uint4 w4 = make_uint4(pend_w[0], pend_w[1], pend_w[2], pend_w[3]);
                 *reinterpret_cast<uint4*>(A.stash + (uint64_t)(uint32_t)(j0 < e ? j0 : 0) * LPE + cp * 4) = w4;
@@ -1073,14 +1080,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const vnf<N> gs = ge * select_pos<N>(s, ac, acs);        // ge * a * LReLU'(s)
                 ga += ge * lrelu_n<N>(s, A.slope);
                 gpr += gs;
-                uint32_t bits = 0;
+                if constexpr (MSG) {
+                    pend_m[u] = g * al[u] + gs;                          // d/dPL[src] from this edge (E:859-869)
+                } else {
+                    uint32_t bits = 0;
 #pragma unroll
-                for (int i = 0; i < N; ++i) bits |= (s[i] > 0.f ? 1u : 0u) << i;
-                const uint32_t w = __builtin_bit_cast(uint32_t, (cp & 1) ? ge : al[u]);
-                pend_w[u] = ((w + (1u << (N - 1))) & ~((1u << N) - 1u)) | bits;
+                    for (int i = 0; i < N; ++i) bits |= (s[i] > 0.f ? 1u : 0u) << i;
+                    const uint32_t w = __builtin_bit_cast(uint32_t, (cp & 1) ? ge : al[u]);
+                    pend_w[u] = ((w + (1u << (N - 1))) & ~((1u << N) - 1u)) | bits;
+                }
             }
         }
-        if constexpr (DBG != 1 && DBG != 3) {
+        if constexpr (MSG) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) store_row_n<HD, N, BF>(A.msg, (int)pend_s[u], cp, pend_m[u]);              // the last step's rows
+        } else if constexpr (DBG != 1 && DBG != 3) {
 #pragma unroll
             for (int u = 0; u < U; ++u) stream_store(&A.stash[(uint64_t)pend_s[u] * LPE + cp], pend_w[u]);      // the last step's records
         }
@@ -1099,6 +1113,194 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (threadIdx.x < HD)
         A.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT (GAT_DBG=4, H*D = 64, D = 8, fp32): wave-specialised record stores.
+// Blocks of NCW compute waves + ONE storing wave.  A compute wave runs the step body of edge_bwd3_kernel but hands the
+// step's 16 records (+ their slots) to the storing wave through a ring in LDS instead of issuing global stores, so that its
+// vmcnt queue holds loads only; the storing wave drains the rings with ONE global_store_dwordx4 per step (4 lanes per
+// 64-byte record, 16 records per instruction, instead of four dword stores of 4 records each).  Hand-off: per compute wave
+// a head word (steps published) and a tail word (steps drained) in LDS; LDS executes a CU's instructions in order, so a
+// reader that sees the new head sees the data written before it, and a tail written after the data reads were issued
+// cannot be overtaken by the producer's next writes.  Every poll loop is bounded (no grid can hang on a lost update).
+// Results are bitwise those of edge_bwd3_kernel (same arithmetic, same records).
+template <int NCW, int R>
+struct RecRing {
+    uint32_t rec[NCW][R][16 * 16];      // 16 records of 16 words per step
+    uint32_t slot[NCW][R][16];
+    int head[NCW], tail[NCW], done[NCW];
+};
+template <int NCW, int R>
+__global__ __launch_bounds__((NCW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void edge_bwd4_kernel(EdgeBwdArgs A) {
+    constexpr int HD = 64, D = 8, N = 4;
+    constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
+    constexpr int U = 4;
+    __shared__ float red[NCW][HD];
+    __shared__ RecRing<NCW, R> ring;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x < NCW) { ring.head[threadIdx.x] = 0; ring.tail[threadIdx.x] = 0; ring.done[threadIdx.x] = 0; }
+    __syncthreads();
+    constexpr int kSpinMax = 1 << 20;
+    if (wave == NCW) {                               // ---- the storing wave ----
+        int drained[NCW];
+#pragma unroll
+        for (int w = 0; w < NCW; ++w) drained[w] = 0;
+        int idle = 0;
+        for (;;) {
+            bool any = false, all_done = true;
+#pragma unroll
+            for (int w = 0; w < NCW; ++w) {
+                const int fin = __hip_atomic_load(&ring.done[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int hd = __hip_atomic_load(&ring.head[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+                if (hd > drained[w]) {
+                    const int rs = drained[w] % R;
+                    const uint4 v = *reinterpret_cast<const uint4*>(&ring.rec[w][rs][lane * 4]);    // record lane/4, quarter lane%4
+                    const uint32_t sl = ring.slot[w][rs][lane >> 2];
+                    asm volatile("" ::: "memory");
+                    ++drained[w];
+                    __hip_atomic_store(&ring.tail[w], drained[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    *reinterpret_cast<uint4*>(A.stash + (uint64_t)sl * LPE + (lane & 3) * 4) = v;
+                    any = true;
+                }
+                if (!fin || hd > drained[w]) all_done = false;
+            }
+            if (all_done) break;
+            if (!any) { __builtin_amdgcn_s_sleep(2); if (++idle > kSpinMax) break; } else idle = 0;
+        }
+    } else {                                         // ---- compute waves ----
+        const int cp = lane % LPE, gidx = lane / LPE;
+        const int c = N * cp;
+        const vnf<N> ac = *reinterpret_cast<const vnf<N>*>(A.a + c);
+        const vnf<N> acs = ac * A.slope;
+        const vnf<N> ac2 = ac * kLog2e;
+        const int64_t nquads = (A.n_items + G - 1) / G;
+        const int64_t nwaves = (int64_t)gridDim.x * NCW;
+        vnf<N> ga = vzero<N>();
+        int published = 0, tail_seen = 0;
+        for (int64_t q = (int64_t)blockIdx.x * NCW + wave; q < nquads; q += nwaves) {
+            const int64_t it = q * G + gidx;
+            int row = -1, b = 0, e = 0, slot = -1;
+            if (it < A.n_items) { const int4 item = A.items[it]; row = item.x; b = item.y; e = item.z; slot = item.w; }
+            const int64_t rowc = row < 0 ? 0 : row;
+            auto load_idx = [&](int st, int& srcv, int& posv) {
+                int j = b + st * U + (cp & (U - 1));
+                j = j < e ? j : e - 1;
+                j = j > 0 ? j : 0;
+                srcv = A.col_idx[j];
+                posv = A.pos[j];
+            };
+            auto spread = [&](int st, int srcv, int posv, int (&src)[U], uint32_t (&sl)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    src[u] = __shfl(srcv, gidx * LPE + u);
+                    const uint32_t p = (uint32_t)__shfl(posv, gidx * LPE + u);
+                    sl[u] = (b + st * U + u < e) ? p : A.stash_spare;
+                }
+            };
+            int srcv, posv, srcn, posn;
+            load_idx(0, srcv, posv);
+            load_idx(1, srcn, posn);
+            const vnf<N> hp = *reinterpret_cast<const vnf<N>*>(A.hpre + rowc * HD + c);
+            vnf<N> dsel;
+#pragma unroll
+            for (int i = 0; i < N; ++i) dsel[i] = hp[i] > 0.f ? 1.0f : A.slope;
+            vnf<N> g;
+            if (A.gh != nullptr) g = *reinterpret_cast<const vnf<N>*>(A.gh + rowc * A.gh_stride + (c % D)) * dsel * (1.0f / (float)H);
+            else {
+                g = *reinterpret_cast<const vnf<N>*>(A.g + rowc * HD + c);
+                if (A.g_raw) g = g * dsel;
+            }
+            const vnf<N> pr = *reinterpret_cast<const vnf<N>*>(A.PR + rowc * HD + c);
+            const float dot = group_sum<DL>(hsum<N>(g * hp));
+            const float m2 = A.mstat[rowc * H + c / D];
+            const float inv = __builtin_amdgcn_rcpf(A.zstat[rowc * H + c / D] + 1e-8f);
+            if (row >= 0 && (slot < 0 || b == A.row_ptr[rowc])) {
+                if (A.hbits != nullptr) {
+                    uint32_t nib = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) nib |= (hp[i] > 0.f ? 1u : 0u) << i;
+                    A.hbits[rowc * A.hb_stride + cp] = (uint8_t)nib;
+                } else {
+                    stream_store(reinterpret_cast<vnf<N>*>(A.gfull + rowc * HD + c), g);
+                }
+            }
+            vnf<N> gpr = vzero<N>();
+            const int nst = wave_max_over_groups<HD, N>((e - b + U - 1) / U);
+            int src[U];
+            uint32_t sl[U];
+            spread(0, srcv, posv, src, sl);
+            for (int st = 0; st < nst; ++st) {
+                vnf<N> v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = gather_row_n<HD, N, false>(A.PL, src[u], cp);
+                uint32_t cur_s[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) cur_s[u] = sl[u];
+                spread(st + 1, srcn, posn, src, sl);
+                load_idx(st + 2, srcn, posn);
+                float al[U], ga_[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) al[u] = hsum<N>(ac2 * lrelu_n<N>(v[u] + pr, A.slope));
+                group_sum_n<DL, U>(al);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    al[u] = exp2_fast(al[u] - m2) * inv;
+                    ga_[u] = hsum<N>(g * v[u]);
+                }
+                group_sum_n<DL, U>(ga_);
+                uint32_t wrd[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool valid = b + st * U + u < e;
+                    const float ge = valid ? al[u] * (ga_[u] - dot) : 0.f;
+                    const vnf<N> s = v[u] + pr;
+                    const vnf<N> gs = ge * select_pos<N>(s, ac, acs);
+                    ga += ge * lrelu_n<N>(s, A.slope);
+                    gpr += gs;
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) bits |= (s[i] > 0.f ? 1u : 0u) << i;
+                    const uint32_t w = __builtin_bit_cast(uint32_t, (cp & 1) ? ge : al[u]);
+                    wrd[u] = ((w + (1u << (N - 1))) & ~((1u << N) - 1u)) | bits;
+                }
+                // hand the step's records to the storing wave: wait for a free ring slot (bounded), write, publish
+                for (int spin = 0; published - tail_seen >= R && spin < kSpinMax; ++spin) {
+                    tail_seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ring.tail[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (published - tail_seen >= R) __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+                const int rs = published % R;
+#pragma unroll
+                for (int u = 0; u < U; ++u) ring.rec[wave][rs][(u * G + gidx) * 16 + cp] = wrd[u];
+                ring.slot[wave][rs][(cp & 3) * G + gidx] = (cp & 2) ? ((cp & 1) ? cur_s[3] : cur_s[2]) : ((cp & 1) ? cur_s[1] : cur_s[0]);
+                asm volatile("" ::: "memory");
+                ++published;
+                if (lane == 0) __hip_atomic_store(&ring.head[wave], published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (row >= 0) {
+                float* dst = slot < 0 ? A.gPR + rowc * HD + c : A.part_acc + (int64_t)slot * HD + c;
+                stream_store(reinterpret_cast<vnf<N>*>(dst), gpr);
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&ring.done[wave], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int off = LPE; off < 64; off <<= 1) ga += shfl_xor_n<N>(ga, off);
+        if (gidx == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) red[wave][c + i] = ga[i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < HD) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NCW; ++w) t += red[w][threadIdx.x];
+        A.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] = t;
+    }
 }
 
 // gPR of split rows: sum of the row's segment partials in segment order (one thread per channel).
@@ -1330,6 +1532,11 @@ static int resident_blocks(const void* fn) {
     return cache[fn] = per_cu * (cus > 0 ? cus : 256);
 }
 static bool packed_backward() { return packed_layout(); }
+// GAT_GROUP_MSG=0: message-row layers on the wave-per-row kernel (edge_bwd2_kernel) instead of the group-per-row one (A/B)
+static bool group_msg() {
+    static const bool v = [] { const char* e = getenv("GAT_GROUP_MSG"); return !(e && e[0] == '0'); }();
+    return v;
+}
 struct BwdSel { bool store, taps, bf16, stash; };
 template <int HD, int D, bool BF>
 const void* bwd_variant(bool store, bool taps, bool stash = false) {
@@ -1338,6 +1545,9 @@ const void* bwd_variant(bool store, bool taps, bool stash = false) {
             if (BF) return (const void*)edge_bwd3_kernel<HD, D, stash_n<HD, D>(), 0, true>;
             return row_groups() ? (const void*)edge_bwd3_kernel<HD, D, stash_n<HD, D>()> : (const void*)edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>;
         }
+    }
+    if constexpr (stash_n<HD, D>() != 0) {        // message rows from the group-per-row kernel
+        if (store && !taps && packed_backward() && row_groups() && group_msg()) return (const void*)edge_bwd3_kernel<HD, D, stash_n<HD, D>(), 0, BF, true>;
     }
     if constexpr (D % 2 == 0) {
         if (store && !taps && packed_backward()) {
@@ -1375,7 +1585,9 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
             if (a.gfull == nullptr || a.pos == nullptr) return fail(GAT_E_INVALID, "edge_backward: stash path needs gfull and pos");
             bool dbg_done = false;
             if constexpr (HD == 64 && D == 8) {      // timing experiments (GAT_DBG=1: no record store, 2: records in CSR order)
-                if (a.dbg == 3 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 3>), grid, block, 0, s, a); dbg_done = true; }
+                if (a.dbg == 4 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<7, 4>), grid, dim3(512), 0, s, a); dbg_done = true; }   // wave-specialised stores: 7 + 1 waves
+                else if (a.dbg == 5 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4>), grid, dim3(256), 0, s, a); dbg_done = true; }   // 3 + 1 waves
+                else if (a.dbg == 3 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 3>), grid, block, 0, s, a); dbg_done = true; }
                 else if (a.dbg == 1 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 1>), grid, block, 0, s, a); dbg_done = true; }
                 else if (a.dbg == 2 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 2>), grid, block, 0, s, a); dbg_done = true; }
                 else if (a.dbg == 1) { hipLaunchKernelGGL((edge_bwd2s_kernel<64, 8, 4, 1>), grid, block, 0, s, a); dbg_done = true; }
@@ -1385,6 +1597,13 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
                 if (row_groups()) hipLaunchKernelGGL((edge_bwd3_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
                 else hipLaunchKernelGGL((edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
             }
+            launched = true;
+        }
+    }
+    if constexpr (stash_n<HD, D>() != 0) {
+        if (!launched && store && !taps && packed_backward() && row_groups() && group_msg()) {
+            if (a.bf16) hipLaunchKernelGGL((edge_bwd3_kernel<HD, D, stash_n<HD, D>(), 0, true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((edge_bwd3_kernel<HD, D, stash_n<HD, D>(), 0, false, true>), grid, block, 0, s, a);
             launched = true;
         }
     }
@@ -1481,7 +1700,10 @@ int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D_, bool store, boo
         GAT_DISPATCH_HD_D(bwd_resident, sel, nullptr)
         return 2048;                                  // generic path: one wave per block
     };
-    const int c = cap();
+    int c = cap();
+    // GAT_DBG=4 (experiment): 512-thread blocks of edge_bwd4_kernel — two resident per CU instead of four
+    static const int dbg = [] { const char* e = getenv("GAT_DBG"); return e ? atoi(e) : 0; }();
+    if (dbg == 4 && HD == 64 && D == 8 && stash && !bf16 && !taps) c = c / 2;
     return (int)(want < c ? want : c);
 }
 

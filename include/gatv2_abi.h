@@ -94,11 +94,13 @@ enum {
     GAT_PATH_GENERIC_SIZE = 2     /* the shape has fast kernels, but the gathered table is >= 4 GiB */
 };
 int gat_layer_path(gat_ctx* ctx, int32_t layer, int32_t* path);
-/* Non-finite inputs: the reference's plain fp32 loops (E:303-316) turn a +-inf feature into +-inf or NaN sums and a
- * non-finite loss.  Here the dense products cut every fp32 operand into three bf16 pieces (x - bf16(x) is inf - inf for an
- * infinite x), so a non-finite — or within half a bf16 ulp of FLT_MAX — feature or weight yields NaN where the reference may
- * yield +-inf: the loss is non-finite in both, the kind of non-finite value may differ.  Nothing hangs or faults
- * (tests/test_nonfinite.py). */
+/* Non-finite inputs: the reference's plain fp32 loops (E:303-316) turn a +-inf feature into +-inf or NaN sums; every row
+ * that aggregates the node within the model's layers ends with NaN class probabilities, and the loss stays finite because
+ * E:527 clamps with fmaxf(prob, 1e-12f), which drops a NaN.  Here the dense products cut every fp32 operand into three bf16
+ * pieces (x - bf16(x) is inf - inf for an infinite x), so a non-finite — or within half a bf16 ulp of FLT_MAX — feature or
+ * weight yields NaN at once where the reference may still hold +-inf: a row the reference rescues (an edge whose score is
+ * -inf gets attention 0 there) can be NaN here.  The poisoned rows are a superset of the reference's and a subset of the
+ * node's L-hop neighbourhood; all other rows are unaffected; nothing hangs or faults (tests/test_nonfinite.py). */
 int gat_set_features(gat_ctx* ctx, const float* x, int64_t n_rows, int32_t in_dim);   /* [n_rows][F0] */
 int gat_set_labels(gat_ctx* ctx, const int32_t* labels, int64_t n_rows);
 /* Train / validation / test splits — beyond the reference, which trains and evaluates on ALL nodes (E:514-537,

@@ -1,6 +1,7 @@
 """Behaviour at the boundary for inputs the parity fixtures never hold:
-  * a non-finite feature gives a non-finite loss — NaN here where the reference's fp32 loops (E:303-316) may give +-inf,
-    see gatv2_abi.h at gat_set_features — and nothing hangs or faults;
+  * a non-finite feature poisons exactly what it can reach, as in the reference, and nothing hangs or faults (the kind of
+    non-finite value differs: NaN here where the reference's fp32 loops, E:303-316, may hold +-inf — gatv2_abi.h at
+    gat_set_features);
   * a source table of 4 GiB or more drops a layer to the generic kernels, and says so (gat_layer_path + a "warning:" text);
   * labels replaced after a training mask are masked again;
   * a replicated-input shard with F > 128 and n_rows < 32641 <= n_table projects both halves correctly (the split-K
@@ -24,24 +25,50 @@ def _ctx(pkg, heads=(8, 8), outdims=(8, 8), n=200, e=1500, f=12, c=4, seed=2, **
 
 
 @pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan, 3.4e38])
-def test_nonfinite_feature_gives_nonfinite_loss_not_a_hang(pkg, bad):
+def test_nonfinite_feature_poisons_its_two_hop_neighbourhood_and_nothing_else(pkg, orc, bad):
+    """What the reference does with a non-finite feature (its plain fp32 loops, restated by the oracle): the node's
+    projections become +-inf / NaN, every row that aggregates it within two layers ends with NaN probabilities, and the
+    loss stays FINITE because E:527 clamps with fmaxf(prob, 1e-12f), which drops a NaN.  Here: the same, except that
+    the three-piece dense product turns +-inf into NaN at once — so a row the reference rescues (an edge whose score
+    is -inf gets alpha = 0 there) can be NaN here.  Asserted: the step returns; the poisoned rows are a superset of
+    the oracle's and a subset of the two-hop neighbourhood; every other row agrees at 1e-4; the context stays usable."""
+    A = pkg.abi
     ctx, rp, ci, x, lab = _ctx(pkg)
+    n = len(lab)
     with ctx:
         x[17, 3] = bad
         if bad == 3.4e38:
             x[17, :] = bad                       # within half a bf16 ulp of FLT_MAX: the three-piece cut overflows (documented)
         ctx.set_features(x); ctx.set_labels(lab)
-        ctx.params_init(1); ctx.zero_grad()
-        loss, correct = ctx.step()
-        assert not np.isfinite(loss), loss        # the reference: +-inf or NaN; here NaN — non-finite either way
-        assert 0 <= correct <= len(lab)
-        g = ctx.grads_get(pkg.abi.PARAM_W)
-        assert g.shape[0] > 0                     # the step completed and the buffers are readable
-        # the context stays usable: finite features again -> finite loss
+        cfg = orc.Config([8, 8], [8, 8], x.shape[1], 4)
+        W, a, Wo = orc.xavier_params(cfg, 1)
+        for g, arr in enumerate((W, a, Wo)):
+            ctx.params_set(g, arr)
+        ctx.zero_grad()
+        loss, correct = ctx.step()                # returns: nothing hangs or faults
+        assert 0 <= correct <= n
+        y = ctx.tap(A.TAP_Y)
+        with np.errstate(all="ignore"):
+            ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo, backward=False)
+        mine = ~np.isfinite(y).all(1)
+        theirs = ~np.isfinite(ref.y).all(1)
+        dst = np.repeat(np.arange(n), np.diff(rp))
+        hop1 = np.zeros(n, bool); hop1[17] = True; hop1[dst[ci == 17]] = True
+        hop2 = hop1.copy(); hop2[dst[hop1[ci]]] = True
+        assert mine[17] and theirs[17]
+        assert not (theirs & ~mine).any(), "a row the reference poisons is clean here"
+        assert not (mine & ~hop2).any(), "a row outside the two-hop neighbourhood is poisoned"
+        ok = ~mine & ~theirs
+        assert ok.sum() > 0 and np.abs(y[ok] - ref.y[ok]).max() < 1e-4
+        if (mine == theirs).all():                # same poisoned set => same clamped loss (E:527)
+            assert np.isfinite(loss) and abs(loss - ref.loss_sum_f64) < 1e-4 * n
+        assert ctx.grads_get(A.PARAM_W).shape[0] > 0
+        # the context stays usable: finite features again -> finite loss equal to a clean run
         x[17, :] = 0.5
         ctx.set_features(x); ctx.zero_grad()
         loss2, _ = ctx.step()
-        assert np.isfinite(loss2)
+        ref2 = orc.step(cfg, rp, ci, lab, x, W, a, Wo, backward=False)
+        assert np.isfinite(loss2) and abs(loss2 - ref2.loss_sum_f64) < 1e-4 * n
 
 
 def test_labels_set_after_a_train_mask_are_masked_again(pkg):
