@@ -154,6 +154,19 @@ def _declare(lib: C.CDLL) -> None:
         "gat_op_csr_to_coo": [vp, vp, vp, vp, i64, i64, vp],
         "gat_op_layer_forward": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, f32, vp],
         "gat_op_layer_backward": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, f32, vp],
+        "gat_op_edge_score": [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i64, f32, vp],
+        "gat_op_max_sum": [vp, vp, i64, i32, i64, vp, vp, vp],
+        "gat_op_attn_coeff": [vp, vp, vp, vp, vp, vp, i64, i32, i64, vp],
+        "gat_op_aggregate": [vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, i32, vp],
+        "gat_op_post_activation": [vp, vp, i64, i32, i32, i32, f32, vp],
+        "gat_op_output_head": [vp, vp, vp, vp, i64, i32, i32, vp],
+        "gat_op_loss_accuracy": [vp, vp, vp, vp, i64, i32, vp],
+        "gat_op_output_gradients": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp],
+        "gat_op_grad_attn_coeff": [i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp],
+        "gat_op_grad_attn_score": [vp, vp, vp, vp, vp, i64, i32, i64, vp],
+        "gat_op_grad_parameters": [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i64, vp],
+        "gat_op_features_input_gradients": [i64, i32, i64, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "gat_op_preact_gradient": [i64, f32, i32, vp, vp, vp],
         "gat_kernel_stats": [vp, C.c_int, P(i64), P(C.c_double)],
         "gat_kernel_stats_reset": [vp],
         "gat_algorithmic_bytes": [vp, P(C.c_double), P(C.c_double)],

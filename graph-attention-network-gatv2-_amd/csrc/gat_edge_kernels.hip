@@ -1131,7 +1131,10 @@ struct RecRing {
     uint32_t slot[NCW][R][16];
     int head[NCW], tail[NCW], done[NCW];
 };
-template <int NCW, int R>
+// POLICY: cache policy of the record stores — 0 plain; 1 `sc1` (write-through, the line is not kept in the XCD's L2:
+// MI355X_MICROARCH.md, stores of each flavour); 2 `sc0 sc1`; 3 `nt`.  A/B of whether partial-line (64 of 128 bytes) record
+// writes cost fills / write-allocation in L2.
+template <int NCW, int R, int POLICY = 0>
 __global__ __launch_bounds__((NCW + 1) * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void edge_bwd4_kernel(EdgeBwdArgs A) {
     constexpr int HD = 64, D = 8, N = 4;
     constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
@@ -1162,7 +1165,13 @@ __global__ __launch_bounds__((NCW + 1) * 64) __attribute__((amdgpu_waves_per_eu(
                     asm volatile("" ::: "memory");
                     ++drained[w];
                     __hip_atomic_store(&ring.tail[w], drained[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    *reinterpret_cast<uint4*>(A.stash + (uint64_t)sl * LPE + (lane & 3) * 4) = v;
+                    uint32_t* dstp = A.stash + (uint64_t)sl * LPE + (lane & 3) * 4;
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                    const u4 vv = {v.x, v.y, v.z, v.w};
+                    if constexpr (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dstp), "v"(vv) : "memory");
+                    else if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dstp), "v"(vv) : "memory");
+                    else if constexpr (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dstp), "v"(vv) : "memory");
+                    else *reinterpret_cast<uint4*>(dstp) = v;
                     any = true;
                 }
                 if (!fin || hd > drained[w]) all_done = false;
@@ -1586,6 +1595,9 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
             bool dbg_done = false;
             if constexpr (HD == 64 && D == 8) {      // timing experiments (GAT_DBG=1: no record store, 2: records in CSR order)
                 if (a.dbg == 4 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<7, 4>), grid, dim3(512), 0, s, a); dbg_done = true; }   // wave-specialised stores: 7 + 1 waves
+                else if (a.dbg == 6 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4, 1>), grid, dim3(256), 0, s, a); dbg_done = true; }   // 3 + 1 waves, sc1 stores
+                else if (a.dbg == 7 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4, 2>), grid, dim3(256), 0, s, a); dbg_done = true; }   // sc0 sc1
+                else if (a.dbg == 8 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4, 3>), grid, dim3(256), 0, s, a); dbg_done = true; }   // nt
                 else if (a.dbg == 5 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4>), grid, dim3(256), 0, s, a); dbg_done = true; }   // 3 + 1 waves
                 else if (a.dbg == 3 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 3>), grid, block, 0, s, a); dbg_done = true; }
                 else if (a.dbg == 1 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 1>), grid, block, 0, s, a); dbg_done = true; }

@@ -233,8 +233,8 @@ enum {
 };
 int gat_tap(gat_ctx* ctx, int tensor, int32_t layer, void* host_dst, int64_t count);
 
-/* ---- op-level entry points: one per reference kernel, caller-provided DEVICE pointers in the
- *      reference layouts (unit parity).  `stream` may be NULL (default stream). ---------------- */
+/* ---- op-level entry points, whole layers: caller-provided DEVICE pointers in the reference layouts
+ *      (unit parity).  `stream` may be NULL (default stream).  One entry point per reference KERNEL: below. ---- */
 /* a1  csr_to_coo_kernel E:67-84 */
 int gat_op_csr_to_coo(const int32_t* d_row_ptr, const int32_t* d_col_idx, int32_t* d_src,
                       int32_t* d_dst, int64_t n_rows, int64_t n_edges, void* stream);
@@ -251,6 +251,67 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
                           const float* d_hpre, const float* d_g, float* d_grad_w, float* d_grad_a,
                           const float* d_hpre_prev, float* d_g_prev, int64_t n, int64_t e,
                           int32_t f, int32_t h, int32_t d, float slope, void* stream);
+
+/* ---- per-kernel entry points: ONE per reference kernel of the hot path, each with the argument list of the launch it
+ *      replaces (node / edge counts widened to 64 bit, a stream appended; `n` added where the reference kernel reads the
+ *      node count only through its indices).  Caller-owned DEVICE pointers in the reference layouts: edge tensors [H][E]
+ *      head-major, node tensors [N][H][D], W [H][D][2F], a [H][D].  Accumulate-or-overwrite behaviour is the reference's.
+ *      A maintainer can swap a single launch of the reference's main() for the matching call and keep everything else
+ *      (INTEGRATION.md §2b).  Scratch (projected features, message tables) is allocated per call; calls synchronise their
+ *      stream.  Scatters use float atomics like the reference's own kernels (sums over edges order-dependent at fp32
+ *      round-off).  csrc/gat_ops.hip. -------------------------------------------------------------------------------- */
+/* a2  gatv2_edge_score_kernel E:279-324, launch E:1386: attn_score[h][e] (overwritten) */
+int gat_op_edge_score(const float* d_input_features, const int32_t* d_col_idx, const int32_t* d_dst, const float* d_w,
+                      const float* d_a, float* d_attn_score, int64_t n, int32_t in_dim, int32_t out_dim, int32_t h,
+                      int64_t e, float negative_slope, void* stream);
+/* a3  compute_max_sum_attn_score E:326-359, launch E:1394-1398: max_score / score_sum at index n*h + dst (overwritten);
+ *     zero in-degree rows give max = -1e9f, sum = 0 (E:336) */
+int gat_op_max_sum(const int32_t* d_row_ptr, const float* d_attn_score, int64_t n, int32_t h, int64_t e,
+                   float* d_max_score, float* d_score_sum, void* stream);
+/* a4  compute_attn_coeff E:362-384, launch E:1407 (d_col_idx is carried by the reference's signature and unused there too) */
+int gat_op_attn_coeff(const int32_t* d_col_idx, const int32_t* d_dst, const float* d_attn_score, const float* d_max_attn_score,
+                      const float* d_sum_score_exp, float* d_attn_coeff, int64_t e, int32_t h, int64_t n, void* stream);
+/* a5  aggregate_kernel E:386-424, launch E:1416: ADDS into d_out_feat [N][H][D] (the caller zeroes it) */
+int gat_op_aggregate(const int32_t* d_src, const int32_t* d_dst, const float* d_attn_coeff, const float* d_in_feat,
+                     const float* d_w, float* d_out_feat, int64_t n, int32_t h, int64_t e, int32_t in_dim, int32_t out_dim,
+                     void* stream);
+/* a6  postActivationLayerOutput E:426-459, launch E:1428: d_H [N][H*D], or [N][D] (mean over heads) when is_last_layer */
+int gat_op_post_activation(const float* d_out_feat, float* d_H, int64_t n, int32_t h, int32_t out_dim, int32_t is_last_layer,
+                           float negative_slope, void* stream);
+/* C12 gatv2_output_kernel E:463-512 (+ softmax E:132-141), launch E:1446: d_z and d_y [N][C] both receive the
+ *     probabilities, as in the reference */
+int gat_op_output_head(const float* d_wo, const float* d_last_layer_output, float* d_z, float* d_y, int64_t num_nodes, int32_t c,
+                       int32_t out_dim_last_layer, void* stream);
+/* C13 compute_loss_accuracy_kernel E:514-537, launch E:1457: per-node loss / correct arrays (summed by the caller, E:542) */
+int gat_op_loss_accuracy(const float* d_y, const int32_t* d_labels, float* d_losses, int32_t* d_corrects, int64_t n, int32_t c,
+                         void* stream);
+/* C14 compute_output_gradients E:553-608, launch E:1468: ADDS into grad_d_wo [C][D_L]; writes grad_d_hL [N][H][D_L].
+ *     flat_lrelu_index: 0 = the exact per-head LReLU' index, 1 = the reference's n*D_L + d (E:598) */
+int gat_op_output_gradients(const float* d_y, const int32_t* d_labels, const float* d_hL, const float* d_HL, const float* d_wo,
+                            float* grad_d_wo, float* grad_d_hL, int64_t n, int32_t c, int32_t out_dim_l, int32_t num_heads,
+                            float negative_slope, int32_t flat_lrelu_index, void* stream);
+/* a7  kernel_grad_atten_coeff E:612-651, launch E:1489: grad_attn_coeff[h][e] (overwritten) */
+int gat_op_grad_attn_coeff(int64_t num_edges, int32_t num_heads, int32_t in_dim, int32_t out_dim, const int32_t* d_src,
+                           const int32_t* d_dst, const float* d_features, const float* d_w, const float* d_grad_input,
+                           float* d_grad_attn_coeff, int64_t n, void* stream);
+/* a8  compute_grad_attn_score_kernel E:654-696, launch E:1499-1506: grad_attn_score[h][e] (overwritten); one pass per row
+ *     instead of the reference's O(deg) loop per edge (same sums up to fp32 order) */
+int gat_op_grad_attn_score(const int32_t* d_row_ptr, const int32_t* d_dst, const float* d_alpha, const float* d_grad_alpha,
+                           float* d_grad_e, int64_t n, int32_t h, int64_t e, void* stream);
+/* a9  compute_grad_parameters_kernel E:698-798, launch E:1517: ADDS into grad_w [H][D][2F] and grad_a [H][D] */
+int gat_op_grad_parameters(int64_t e, int32_t h, const int32_t* d_src, const int32_t* d_dst, const float* d_features,
+                           const float* d_input_gradients, const float* d_grad_attn_score, const float* d_attn_coeff,
+                           const float* d_w, const float* d_a, float* grad_w, float* grad_a, int32_t in_dim, int32_t out_dim,
+                           float negative_slope, int64_t n, void* stream);
+/* a10 compute_features_input_gradients E:801-874, launch E:1533: ADDS into grad_x_features [N][F] (zeroed per epoch, E:1636) */
+int gat_op_features_input_gradients(int64_t n, int32_t h, int64_t e, int32_t in_dim, int32_t out_dim, float negative_slope,
+                                    const int32_t* d_src, const int32_t* d_dst, const float* d_attn_coeff,
+                                    const float* d_input_features, const float* d_w, const float* d_input_gradients,
+                                    const float* d_grad_attn_score, const float* d_attn_vector, float* d_grad_x_features,
+                                    void* stream);
+/* a11 compute_preActivation_inputFeatures_gradient E:879-893, launch E:1546: in place on input_features_gradients [N][F] */
+int gat_op_preact_gradient(int64_t n, float negative_slope, int32_t in_dim, const float* d_pre_activation_input_features,
+                           float* d_input_features_gradients, void* stream);
 
 /* ---- synthetic workloads on the device --------------------------------------------
  * The reference's datasets are a download link (README R:21); every BASELINE workload here is a deterministic
