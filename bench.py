@@ -311,6 +311,15 @@ def main():
             per_launch_bytes = bytes_k[dom] * args.steps / launches
             avg_ms = tot_ms / launches
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        # SURVEY 8d's byte count prices an attn_coeff write (forward) and read (backward) of E*H elements per layer that the
+        # training path never performs (alpha is recomputed from the per-row softmax statistics): the same quotients on the
+        # bytes this path's algorithm really needs are reported beside the contract's `frac` — never instead of it
+        b_store = 4 if args.dtype == "f32" else 2
+        alpha_dir = float(sum(e * h * b_store for h in heads)) if runner is None else 0.0
+        tp_bytes_step = bytes_step_all - 2.0 * alpha_dir if runner is None else None
+        pmc_note = ("traffic = L2-to-fabric request bytes (TCC_EA_RDREQ / WRREQ, rocprofv3 PMC): Infinity-Cache hits are counted in it "
+                    "(MI355X_MICROARCH.md, HBM), so it is an upper bound of DRAM bytes, and `frac` / `achieved` are fractions of SURVEY 8d's "
+                    "byte model (which assumes every gathered row misses), not a measured DRAM utilisation")
         line = {
             "metric": "edges/sec (fwd+bwd, 2-layer 8-head GATv2)" if len(heads) == 2 else
                       f"edges/sec (fwd+bwd, {len(heads)}-layer 8-head GATv2)",
@@ -338,14 +347,21 @@ def main():
                               # HBM bytes the step really moves (sum of the PMC passes over all its kernels), and its
                               # ratio to the algorithmic bytes: > 1 = traffic the algorithm does not need
                               "traffic": step_traffic,
-                              "traffic_over_algorithmic": (step_traffic / bytes_step_all) if step_traffic else None},
+                              "traffic_over_algorithmic": (step_traffic / bytes_step_all) if step_traffic else None,
+                              "training_path_GB_per_step": (tp_bytes_step / 1e9) if tp_bytes_step else None,
+                              "frac_training_path": (tp_bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if tp_bytes_step else None,
+                              "note": pmc_note},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world, dom),
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
                          # the kernel's REAL HBM rate (PMC bytes / measured time): what the memory system delivers to it,
                          # whatever share of those bytes the algorithm needs
                          "achieved_traffic_GBps": (measured_traffic(args, world, dom) / (avg_ms * 1e-3) / 1e9)
-                                                  if measured_traffic(args, world, dom) else None} if timed else None,
+                                                  if measured_traffic(args, world, dom) else None,
+                         # the same kernel on the bytes the training path needs (no attn_coeff read / write: see above)
+                         "frac_training_path": ((per_launch_bytes - alpha_dir * args.steps / launches) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                               if (runner is None and dom in ("edge_forward", "edge_backward")) else None,
+                         "note": pmc_note} if timed else None,
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in stats.items() if v[0] > 0},
         }
         if not args.no_cpu_baseline and world == 1:      # CPU lines: rank 0 at N = 1 only (the other ranks would wait in the barrier)

@@ -32,27 +32,33 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--exchange-layer0", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     args = ap.parse_args()
     import torch
     import bench
     pkg = entry.load_package()
     heads, outdims = bench.PRESETS[args.workload]
     n, e, f, c, kind = pkg.synth.SHAPES[args.workload]
-    row_ptr, col_idx = pkg.synth.powerlaw_graph(n, e)
     dev = torch.device("cuda", 0)
+    dsd = pkg.synth.make_dataset_device(args.workload, dev)        # the device generator: bit-for-bit synth.py, seconds instead of minutes
+    row_ptr, col_idx = dsd["row_ptr"], dsd["d_col_idx"].cpu().numpy()
+    x_all, lab_all = dsd["d_x"].cpu().numpy(), dsd["d_labels"].cpu().numpy()
+    del dsd
+    torch.cuda.empty_cache()
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        ctx = pkg.GatContext(heads, outdims, f, c, device=0, stream=stream.cuda_stream, collect_timing=True)
+        ctx = pkg.GatContext(heads, outdims, f, c, device=0, stream=stream.cuda_stream, collect_timing=True, dtype=args.dtype)
         S = pkg.shard
         plan = S.make_plan(row_ptr, args.world, args.rank)
         rp_l, ci_l = S.local_csr(plan, row_ptr, col_idx)
         lo, hi = plan.row0, plan.row0 + plan.n_rows
         ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
         if args.exchange_layer0:
-            ctx.set_features(pkg.synth.features(n, f, rows=(lo, hi), kind=kind))
+            ctx.set_features(x_all[lo:hi])
         else:
-            ctx.set_source_features(plan.table_features(pkg.synth.features(n, f, kind=kind)))
-        ctx.set_labels(pkg.synth.labels(n, c, rows=(lo, hi)))
+            ctx.set_source_features(plan.table_features(x_all))
+        ctx.set_labels(lab_all[lo:hi])
+        del x_all
         run = S.ShardedGat(ctx, plan, NoComm(), heads, outdims,
                            alloc=lambda k: torch.randn(k, dtype=torch.float32, device=dev) * 0.1)
         ctx.params_init(42)
@@ -67,9 +73,15 @@ def main():
         ctx.sync()
         dt = (time.perf_counter() - t0) / args.steps
         stats = ctx.kernel_stats()
-    print(json.dumps({"world": args.world, "rank": args.rank, "rows": plan.n_rows, "edges": int(rp_l[-1]),
+    hd = [h * d for h, d in zip(heads, outdims)]
+    sb = 2 if args.dtype == "bf16" else 4
+    exchanged = range(0 if args.exchange_layer0 else 1, len(heads))
+    print(json.dumps({"workload": args.workload, "dtype": args.dtype, "plan": "all layers exchanged" if args.exchange_layer0 else "input replicated, layer 0 exchange-free",
+                      "world": args.world, "rank": args.rank, "rows": plan.n_rows, "edges": int(rp_l[-1]),
                       "table_rows": plan.n_table, "ms_per_step_compute_only": dt * 1e3,
-                      "exchange_MB_per_table": plan.n_table * 64 * 4 / 1e6,
+                      # bytes every rank RECEIVES per step over xGMI: (world-1)/world of each exchanged table, forward (PL, storage dtype)
+                      # and backward (gPL partial sums, fp32), plus the packed-gradient all-reduce (negligible)
+                      "wire_MB_per_step_per_rank": sum(plan.n_table * hd[l] * (sb + 4) for l in exchanged) * (args.world - 1) / args.world / 1e6,
                       "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in stats.items() if v[0] > 0}}))
     ctx.close()
 
