@@ -301,8 +301,9 @@ static int ensure_buffers(gat_ctx* c) {
     const char* force = getenv("GAT_BWD_ATOMICS");
     if ((msg_hd > 0 || stash_words > 0) && E > 0 && !(force && force[0] == '1')) {
         float* m = nullptr;
-        // E + 1 rows / records: the last one takes the stores of the group-per-row kernels' padded lanes
-        if (hipMalloc((void**)&m, std::max<size_t>((size_t)(E + 1) * msg_hd * (size_t)st_bytes(c), (size_t)(E + 1) * stash_words * sizeof(uint32_t))) == hipSuccess) {
+        // E + 1 rows / records: the last one takes the stores of the group-per-row kernels' padded lanes; kPullPad records of
+        // padding behind the records and the destination list: the pull pass reads whole 16-slot chunks without clamping
+        if (hipMalloc((void**)&m, std::max<size_t>((size_t)(E + 1) * msg_hd * (size_t)st_bytes(c), (size_t)(E + kPullPad) * stash_words * sizeof(uint32_t))) == hipSuccess) {
             c->owned.push_back(m);
             if (msg_hd > 0) { c->msg = m; c->msg_hd = msg_hd; }
             if (stash_words > 0) {                  // records and message rows are never live at the same time: one buffer
@@ -310,7 +311,9 @@ static int ensure_buffers(gat_ctx* c) {
                 if (msg_hd == 0) { c->msg = m; c->msg_hd = 0; }
                 GAT_TRY(dalloc(c, &c->gfull, N * c->HDmax));
                 if (c->layers[L - 1].stash && c->gH != nullptr && c->gh_stride == 16) c->hbits = reinterpret_cast<uint8_t*>(c->gH) + 32;
-                GAT_TRY(dalloc(c, &c->csc_dst, E));
+                GAT_TRY(dalloc(c, &c->csc_dst, E + kPullPad));
+                GAT_HIP(hipMemsetAsync(c->csc_dst + E, 0, (size_t)kPullPad * sizeof(int32_t), c->stream));      // padding: row 0 (any valid row)
+                GAT_HIP(hipMemsetAsync(reinterpret_cast<uint32_t*>(m) + (size_t)E * stash_words, 0, (size_t)kPullPad * stash_words * sizeof(uint32_t), c->stream));
             }
             GAT_TRY(dalloc(c, &c->csc_pos, E));
             GAT_TRY(dalloc(c, &c->csc_ptr, T + 1));
@@ -795,7 +798,8 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     // Arxiv shape 43 MB: the extra loads per slot cost more than the smaller rows save, 1.31 -> 1.25 ms per step without)
     static const int pull_last = [] { const char* e = getenv("GAT_PULL_LAST"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     const bool big_rows = (int64_t)c->n_rows * y.H * y.D * 4 > ((int64_t)128 << 20);
-    const bool last_g = stash && a.gh != nullptr && c->hbits != nullptr && !bf16(c) && (pull_last >= 0 ? pull_last == 1 : big_rows);
+    const bool last_g = stash && a.gh != nullptr && c->hbits != nullptr && !bf16(c) && (pull_last >= 0 ? pull_last == 1 : big_rows) &&
+                        c->n_rows < ((int64_t)1 << 26);             // the pull pass addresses the 64-byte node records with 32-bit offsets
     a.hbits = last_g ? c->hbits : nullptr;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots; a.n_split = c->work.n_split;
     a.part_acc = c->part_acc;

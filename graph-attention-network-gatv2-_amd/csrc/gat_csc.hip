@@ -445,7 +445,85 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range(const uint32_t* __r
     return acc;
 }
 
-template <int HD, int N, bool BF, int LASTD>
+// ---- pull_range, second form (fp32; GAT_PULL_V2=0 selects the first one, A/B) --------------------------------------------
+// The last-layer pass measured VALU-bound (rocprofv3: vector ALU busy on every cycle of the kernel, matrix pipe idle, 44 %
+// of wave time waiting): 62 vector instructions per slot, 45 % of them the and / compare / select triples that turn a
+// decision bit into its multiplier (1 or slope), 12 % 64-bit address arithmetic for the clamped slot index.  Here
+//   * the N decision bits of a word index a table of multiplier vectors in LDS ({1 | slope}^N, 2^N entries, the same for
+//     every lane: lanes with equal bits read the same address, lanes with different bits different banks — conflict-free);
+//   * slots are addressed as a wave-uniform base (advanced per chunk on the scalar unit) + a per-lane byte offset that
+//     is loop-invariant; nothing is clamped: the record and destination arrays carry kPullPad entries of padding, a
+//     slot beyond the list is zeroed after its load (and its gather redirected to the chunk's first row);
+//   * the head's other word comes from a DPP quad permute instead of a cross-lane LDS shuffle.
+// Same sums in the same slot order; the two products of a slot are added one after the other (fma, fma) instead of as one sum.
+template <int N> struct PullTabs { alignas(16) float m[2][1 << N][N]; };     // [0]: bit ? 1 : slope; [1]: the same times 1 / heads
+template <int N>
+__device__ __forceinline__ void pull_tabs_init(PullTabs<N>& T, float slope, float inv_heads) {
+    for (int t = threadIdx.x; t < 2 * (1 << N) * N; t += blockDim.x) {
+        const int tab = t / ((1 << N) * N), nib = (t / N) % (1 << N), k = t % N;
+        const float v = (nib >> k) & 1 ? 1.0f : slope;
+        T.m[tab][nib][k] = tab ? v * inv_heads : v;
+    }
+    __syncthreads();
+}
+template <int HD, int N, int LASTD>
+__device__ __forceinline__ typename PullVec<N>::T pull_range2(const PullTabs<N>& T, const uint32_t* __restrict__ stash,
+                                                              const int32_t* __restrict__ cdst, const float* __restrict__ gfull,
+                                                              const uint8_t* __restrict__ hbits, int b, int e, int lane,
+                                                              typename PullVec<N>::T ac) {
+    using V = typename PullVec<N>::T;
+    constexpr int LPE = HD / N, G = 64 / LPE;
+    constexpr int CH = 16, U = CH / G;
+    constexpr uint32_t kMask = (1u << N) - 1u;
+    static_assert(U >= 1, "lane layout");
+    const int cp = lane % LPE, gidx = lane / LPE;
+    V acc;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = 0.f;
+    const char* sp = reinterpret_cast<const char*>(stash + (uint64_t)(uint32_t)b * LPE);      // wave-uniform
+    const char* dp = reinterpret_cast<const char*>(cdst + b);
+    const uint32_t doff = (uint32_t)(lane & (CH - 1)) * 4u;
+    int dv = *reinterpret_cast<const int32_t*>(dp + doff);
+    for (int rem = e - b; rem > 0; rem -= CH, sp += CH * LPE * 4, dp += CH * 4) {
+        const int dn = *reinterpret_cast<const int32_t*>(dp + CH * 4 + doff);          // next chunk (padding keeps it legal)
+        const int d0 = __builtin_amdgcn_readfirstlane(dv);                              // the chunk's first slot: always inside the list
+        uint32_t w[U];
+        V g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool valid = u * G + gidx < rem;
+            const uint32_t ww = *reinterpret_cast<const uint32_t*>(sp + (uint32_t)((u * G + gidx) * LPE + cp) * 4u);
+            int drow = __shfl(dv, u * G + gidx);
+            drow = valid ? drow : d0;
+            w[u] = valid ? ww : 0u;
+            if constexpr (LASTD > 0) {               // 64-byte node records {gH[8] | - | decision bytes at +32}: one line per slot
+                const uint32_t ro = (uint32_t)drow << 6;
+                const V gh4 = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + (ro + (uint32_t)((cp * N) % LASTD) * 4u));
+                const uint32_t nib = *reinterpret_cast<const uint8_t*>(reinterpret_cast<const char*>(hbits) + (ro + (uint32_t)cp));
+                g[u] = gh4 * *reinterpret_cast<const V*>(&T.m[1][nib & kMask][0]);
+            } else {
+                g[u] = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + ((uint32_t)drow * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4)));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float val = __builtin_bit_cast(float, w[u] & ~kMask);
+            const float oth = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, val), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+            const float al = (cp & 1) ? oth : val, ge = (cp & 1) ? val : oth;
+            const V m1 = *reinterpret_cast<const V*>(&T.m[0][w[u] & kMask][0]);
+            acc += g[u] * al;
+            acc += (ac * ge) * m1;
+        }
+        dv = dn;
+    }
+#pragma unroll
+    for (int off = LPE; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] += __shfl_xor(acc[k], off);
+    return acc;
+}
+
+template <int HD, int N, bool BF, int LASTD, bool V2 = false>
 __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict__ src_ptr, const uint32_t* __restrict__ stash,
                                                        const int32_t* __restrict__ cdst, const float* __restrict__ gfull,
                                                        const uint8_t* __restrict__ hbits, int gh_stride, int hb_stride,
@@ -453,17 +531,20 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
                                                        int64_t n_table, int32_t kHeavySlots) {
     using V = typename PullVec<N>::T;
     constexpr int LPE = HD / N;
+    __shared__ PullTabs<N> tabs;
+    if constexpr (V2) pull_tabs_init<N>(tabs, slope, LASTD > 0 ? 1.0f / (float)(HD / (LASTD > 0 ? LASTD : 1)) : 1.0f);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (s >= n_table) return;
-    const int b = src_ptr[s], e = src_ptr[s + 1];
+    const int b = __builtin_amdgcn_readfirstlane(src_ptr[s]), e = __builtin_amdgcn_readfirstlane(src_ptr[s + 1]);
     if (e - b > kHeavySlots) return;                    // long lists: gpl_pull_chunk_kernel + gpl_heavy_fix_kernel
     const int cp = lane % LPE;
     V acc;
     if (b < e) {
         const V ac = *reinterpret_cast<const V*>(a + cp * N);
-        acc = pull_range<HD, N, BF, LASTD>(stash, cdst, gfull, hbits, gh_stride, hb_stride, slope, b, e, lane, ac, ac * slope);
+        if constexpr (V2) acc = pull_range2<HD, N, LASTD>(tabs, stash, cdst, gfull, hbits, b, e, lane, ac);
+        else acc = pull_range<HD, N, BF, LASTD>(stash, cdst, gfull, hbits, gh_stride, hb_stride, slope, b, e, lane, ac, ac * slope);
     } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = 0.f;
@@ -471,7 +552,7 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
     if (lane < LPE) stream_store(reinterpret_cast<V*>(gPL + s * HD + cp * N), acc);
 }
 
-template <int HD, int N, bool BF, int LASTD>
+template <int HD, int N, bool BF, int LASTD, bool V2 = false>
 __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restrict__ chunks, int32_t n_chunks,
                                                              const uint32_t* __restrict__ stash, const int32_t* __restrict__ cdst,
                                                              const float* __restrict__ gfull, const uint8_t* __restrict__ hbits,
@@ -479,6 +560,8 @@ __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restr
                                                              float slope, float* __restrict__ part) {
     using V = typename PullVec<N>::T;
     constexpr int LPE = HD / N;
+    __shared__ PullTabs<N> tabs;
+    if constexpr (V2) pull_tabs_init<N>(tabs, slope, LASTD > 0 ? 1.0f / (float)(HD / (LASTD > 0 ? LASTD : 1)) : 1.0f);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = blockIdx.x * 4 + wave;
@@ -486,7 +569,9 @@ __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restr
     const int4 ch = chunks[k];                          // {first slot, end slot, partial row, -}, never empty
     const int cp = lane % LPE;
     const V ac = *reinterpret_cast<const V*>(a + cp * N);
-    const V acc = pull_range<HD, N, BF, LASTD>(stash, cdst, gfull, hbits, gh_stride, hb_stride, slope, ch.x, ch.y, lane, ac, ac * slope);
+    V acc;
+    if constexpr (V2) acc = pull_range2<HD, N, LASTD>(tabs, stash, cdst, gfull, hbits, __builtin_amdgcn_readfirstlane(ch.x), __builtin_amdgcn_readfirstlane(ch.y), lane, ac);
+    else acc = pull_range<HD, N, BF, LASTD>(stash, cdst, gfull, hbits, gh_stride, hb_stride, slope, ch.x, ch.y, lane, ac, ac * slope);
     if (lane < LPE) *reinterpret_cast<V*>(part + (int64_t)ch.z * HD + cp * N) = acc;
 }
 
@@ -627,14 +712,25 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
         GAT_HIP(hipGetLastError());
         return 0;
     }
+    // second form of the slot walk (pull_range2): fp32 tables; the last-layer variant needs the 64-byte node records
+    static const bool v2_env = [] { const char* e = getenv("GAT_PULL_V2"); return !(e && e[0] == '0'); }();
+    const bool v2 = v2_env && !BF && (LASTD == 0 || (gh_stride == 16 && hb_stride == 64));
     if (n_heavy > 0) {                                  // long lists first: they are the longest-running waves
-        hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, BF, LASTD>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
-                           stash, cdst, gfull, hbits, gh_stride, hb_stride, a, slope, part);
+        if constexpr (!BF) {
+            if (v2) hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, false, LASTD, true>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
+                                       stash, cdst, gfull, hbits, gh_stride, hb_stride, a, slope, part);
+        }
+        if (!v2) hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, BF, LASTD>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
+                                    stash, cdst, gfull, hbits, gh_stride, hb_stride, a, slope, part);
         const int64_t threads = (int64_t)n_heavy * HD;
         hipLaunchKernelGGL(gpl_heavy_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, heavy, n_heavy, part, gPL, HD);
     }
-    hipLaunchKernelGGL((gpl_pull_kernel<HD, N, BF, LASTD>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
-                       cdst, gfull, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, heavy_slots(n_slots));
+    if constexpr (!BF) {
+        if (v2) hipLaunchKernelGGL((gpl_pull_kernel<HD, N, false, LASTD, true>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
+                                   cdst, gfull, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, heavy_slots(n_slots));
+    }
+    if (!v2) hipLaunchKernelGGL((gpl_pull_kernel<HD, N, BF, LASTD>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
+                                cdst, gfull, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, heavy_slots(n_slots));
     GAT_HIP(hipGetLastError());
     return 0;
 }

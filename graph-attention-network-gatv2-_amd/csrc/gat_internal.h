@@ -140,6 +140,9 @@ int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, int64_t n_edges,
 int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
                    int32_t HD, bool msg_bf16, const int4* chunks, int32_t n_chunks, const int4* heavy,
                    int32_t n_heavy, float* part, hipStream_t s);
+// slots of padding behind the record buffer and the destination list: the pull pass reads whole 16-slot chunks (and one chunk
+// of destinations ahead) without clamping its indices
+constexpr int64_t kPullPad = 32;
 // cdst[pos[e]] = destination row of CSR edge e (the source-major twin of a1's dst array; built once per graph)
 int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int64_t n_rows, int64_t n_edges, hipStream_t s);
 // Stash path: gPL[s][:] = sum over the slots of s of  g[cdst][:] * alpha + ge * a (.) LReLU'  rebuilt from the records
