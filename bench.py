@@ -60,9 +60,11 @@ def parse():
                          "all-gather / reduce-scatter, one all-reduce); 'torch' = the same plan driven from "
                          "shard.ShardedGat over torch.distributed")
     ap.add_argument("--comm-chunks", type=int, default=1,
-                    help="N>1, --comm native: chunk-pipelined forward exchange (gat_comm_option GAT_COMM_PIPELINE); results unchanged")
+                    help="N>1, --comm native: chunk-pipelined forward exchange (gat_comm_option GAT_COMM_PIPELINE); results unchanged.  "
+                         "UNVERIFIED over RCCL beyond world 1 (no multi-GPU box in the build pool): default off")
     ap.add_argument("--gpl-bf16", action="store_true",
-                    help="N>1, --comm native: remote gPL partial sums travel as bf16 (GAT_COMM_GPL_BF16; 1e-2 parity mode, NOT the headline)")
+                    help="N>1, --comm native: remote gPL partial sums travel as bf16 (GAT_COMM_GPL_BF16; 1e-2 parity mode, NOT the headline).  "
+                         "UNVERIFIED over RCCL beyond world 1 (only its host-transport twin is tested at 3 ranks): default off")
     ap.add_argument("--beta", type=float, default=0.75, help="power-law exponent of the degree law (debug)")
     return ap.parse_args()
 

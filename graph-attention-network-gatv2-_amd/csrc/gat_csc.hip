@@ -466,12 +466,37 @@ __device__ __forceinline__ void pull_tabs_init(PullTabs<N>& T, float slope, floa
     }
     __syncthreads();
 }
-template <int HD, int N, int LASTD>
+// bit K of `bits` set ? a : b without a compare: v_bfe_i32 (one bit, sign-extended = the select mask) + v_bfi_b32.  Written
+// as asm, one channel per call: hipcc folds the C form back into v_and + v_cmp + v_cndmask (three instructions), and an asm
+// statement inside a loop over the channel index took element 0 of both vectors for every channel (ROCm 7.2).
+template <int K>
+__device__ __forceinline__ float select_bit(uint32_t bits, float a, float b) {
+    uint32_t mask, sel;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mask) : "v"(bits), "n"(K));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(mask), "v"(__builtin_bit_cast(uint32_t, a)), "v"(__builtin_bit_cast(uint32_t, b)));
+    return __builtin_bit_cast(float, sel);
+}
+template <int N>
+__device__ __forceinline__ typename PullVec<N>::T select_bits(uint32_t bits, typename PullVec<N>::T a, typename PullVec<N>::T b) {
+    typename PullVec<N>::T r;
+    r[0] = select_bit<0>(bits, a[0], b[0]);
+    r[1] = select_bit<1>(bits, a[1], b[1]);
+    if constexpr (N > 2) { r[2] = select_bit<2>(bits, a[2], b[2]); r[3] = select_bit<3>(bits, a[3], b[3]); }
+    return r;
+}
+// TAB: multipliers from the LDS tables (T) — else from select_bits (no LDS, no per-block table set-up)
+template <int HD, int N, int LASTD, bool TAB>
 __device__ __forceinline__ typename PullVec<N>::T pull_range2(const PullTabs<N>& T, const uint32_t* __restrict__ stash,
                                                               const int32_t* __restrict__ cdst, const float* __restrict__ gfull,
                                                               const uint8_t* __restrict__ hbits, int b, int e, int lane,
-                                                              typename PullVec<N>::T ac) {
+                                                              typename PullVec<N>::T ac, float slope) {
     using V = typename PullVec<N>::T;
+    [[maybe_unused]] const V acs = ac * slope;
+    [[maybe_unused]] V mhi, mlo;                      // last layer: 1 / heads and slope / heads
+    if constexpr (LASTD > 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) { mhi[k] = 1.0f / (float)(HD / LASTD); mlo[k] = slope * (1.0f / (float)(HD / LASTD)); }
+    }
     constexpr int LPE = HD / N, G = 64 / LPE;
     constexpr int CH = 16, U = CH / G;
     constexpr uint32_t kMask = (1u << N) - 1u;
@@ -500,7 +525,8 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range2(const PullTabs<N>&
                 const uint32_t ro = (uint32_t)drow << 6;
                 const V gh4 = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + (ro + (uint32_t)((cp * N) % LASTD) * 4u));
                 const uint32_t nib = *reinterpret_cast<const uint8_t*>(reinterpret_cast<const char*>(hbits) + (ro + (uint32_t)cp));
-                g[u] = gh4 * *reinterpret_cast<const V*>(&T.m[1][nib & kMask][0]);
+                if constexpr (TAB) g[u] = gh4 * *reinterpret_cast<const V*>(&T.m[1][nib & kMask][0]);
+                else g[u] = gh4 * select_bits<N>(nib, mhi, mlo);
             } else {
                 g[u] = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + ((uint32_t)drow * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4)));
             }
@@ -510,9 +536,9 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range2(const PullTabs<N>&
             const float val = __builtin_bit_cast(float, w[u] & ~kMask);
             const float oth = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, val), 0xB1, 0xF, 0xF, true));   // lane ^ 1
             const float al = (cp & 1) ? oth : val, ge = (cp & 1) ? val : oth;
-            const V m1 = *reinterpret_cast<const V*>(&T.m[0][w[u] & kMask][0]);
             acc += g[u] * al;
-            acc += (ac * ge) * m1;
+            if constexpr (TAB) acc += (ac * ge) * *reinterpret_cast<const V*>(&T.m[0][w[u] & kMask][0]);
+            else acc += select_bits<N>(w[u], ac, acs) * ge;
         }
         dv = dn;
     }
@@ -523,7 +549,7 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range2(const PullTabs<N>&
     return acc;
 }
 
-template <int HD, int N, bool BF, int LASTD, bool V2 = false>
+template <int HD, int N, bool BF, int LASTD, int V2 = 0>          // V2: 0 first form, 1 second form with LDS tables, 2 second form with bit selects
 __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict__ src_ptr, const uint32_t* __restrict__ stash,
                                                        const int32_t* __restrict__ cdst, const float* __restrict__ gfull,
                                                        const uint8_t* __restrict__ hbits, int gh_stride, int hb_stride,
@@ -532,7 +558,7 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
     using V = typename PullVec<N>::T;
     constexpr int LPE = HD / N;
     __shared__ PullTabs<N> tabs;
-    if constexpr (V2) pull_tabs_init<N>(tabs, slope, LASTD > 0 ? 1.0f / (float)(HD / (LASTD > 0 ? LASTD : 1)) : 1.0f);
+    if constexpr (V2 == 1) pull_tabs_init<N>(tabs, slope, LASTD > 0 ? 1.0f / (float)(HD / (LASTD > 0 ? LASTD : 1)) : 1.0f);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -543,7 +569,7 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
     V acc;
     if (b < e) {
         const V ac = *reinterpret_cast<const V*>(a + cp * N);
-        if constexpr (V2) acc = pull_range2<HD, N, LASTD>(tabs, stash, cdst, gfull, hbits, b, e, lane, ac);
+        if constexpr (V2 != 0) acc = pull_range2<HD, N, LASTD, V2 == 1>(tabs, stash, cdst, gfull, hbits, b, e, lane, ac, slope);
         else acc = pull_range<HD, N, BF, LASTD>(stash, cdst, gfull, hbits, gh_stride, hb_stride, slope, b, e, lane, ac, ac * slope);
     } else {
 #pragma unroll
@@ -552,7 +578,7 @@ __global__ __launch_bounds__(256) void gpl_pull_kernel(const int32_t* __restrict
     if (lane < LPE) stream_store(reinterpret_cast<V*>(gPL + s * HD + cp * N), acc);
 }
 
-template <int HD, int N, bool BF, int LASTD, bool V2 = false>
+template <int HD, int N, bool BF, int LASTD, int V2 = 0>
 __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restrict__ chunks, int32_t n_chunks,
                                                              const uint32_t* __restrict__ stash, const int32_t* __restrict__ cdst,
                                                              const float* __restrict__ gfull, const uint8_t* __restrict__ hbits,
@@ -561,7 +587,7 @@ __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restr
     using V = typename PullVec<N>::T;
     constexpr int LPE = HD / N;
     __shared__ PullTabs<N> tabs;
-    if constexpr (V2) pull_tabs_init<N>(tabs, slope, LASTD > 0 ? 1.0f / (float)(HD / (LASTD > 0 ? LASTD : 1)) : 1.0f);
+    if constexpr (V2 == 1) pull_tabs_init<N>(tabs, slope, LASTD > 0 ? 1.0f / (float)(HD / (LASTD > 0 ? LASTD : 1)) : 1.0f);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = blockIdx.x * 4 + wave;
@@ -570,7 +596,7 @@ __global__ __launch_bounds__(256) void gpl_pull_chunk_kernel(const int4* __restr
     const int cp = lane % LPE;
     const V ac = *reinterpret_cast<const V*>(a + cp * N);
     V acc;
-    if constexpr (V2) acc = pull_range2<HD, N, LASTD>(tabs, stash, cdst, gfull, hbits, __builtin_amdgcn_readfirstlane(ch.x), __builtin_amdgcn_readfirstlane(ch.y), lane, ac);
+    if constexpr (V2 != 0) acc = pull_range2<HD, N, LASTD, V2 == 1>(tabs, stash, cdst, gfull, hbits, __builtin_amdgcn_readfirstlane(ch.x), __builtin_amdgcn_readfirstlane(ch.y), lane, ac, slope);
     else acc = pull_range<HD, N, BF, LASTD>(stash, cdst, gfull, hbits, gh_stride, hb_stride, slope, ch.x, ch.y, lane, ac, ac * slope);
     if (lane < LPE) *reinterpret_cast<V*>(part + (int64_t)ch.z * HD + cp * N) = acc;
 }
@@ -712,25 +738,32 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
         GAT_HIP(hipGetLastError());
         return 0;
     }
-    // second form of the slot walk (pull_range2): fp32 tables; the last-layer variant needs the 64-byte node records
-    static const bool v2_env = [] { const char* e = getenv("GAT_PULL_V2"); return !(e && e[0] == '0'); }();
-    const bool v2 = v2_env && !BF && (LASTD == 0 || (gh_stride == 16 && hb_stride == 64));
-    if (n_heavy > 0) {                                  // long lists first: they are the longest-running waves
-        if constexpr (!BF) {
-            if (v2) hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, false, LASTD, true>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
-                                       stash, cdst, gfull, hbits, gh_stride, hb_stride, a, slope, part);
-        }
-        if (!v2) hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, BF, LASTD>), dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, s, chunks, n_chunks,
-                                    stash, cdst, gfull, hbits, gh_stride, hb_stride, a, slope, part);
-        const int64_t threads = (int64_t)n_heavy * HD;
-        hipLaunchKernelGGL(gpl_heavy_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, heavy, n_heavy, part, gPL, HD);
-    }
+    // second form of the slot walk (pull_range2): fp32 tables; the last-layer variant needs the 64-byte node records.
+    // GAT_PULL_V2 = 0 first form | 1 second form, multipliers from LDS tables | 2 second form, multipliers by bit selects (A/B)
+    // Products shape, same box: 5.01 / 5.89 / 4.78 ms per step for 0 / 1 / 2 — the tables cost every 64-thread block its set-up
+    // and put an LDS round trip behind every record load; the bit selects are the default
+    static const int v2_env = [] { const char* e = getenv("GAT_PULL_V2"); return e ? atoi(e) : 2; }();
+    const int v2 = (!BF && (LASTD == 0 || (gh_stride == 16 && hb_stride == 64))) ? v2_env : 0;
+    const dim3 cgrid((unsigned)((n_chunks + 3) / 4)), pgrid((unsigned)((n_table + wpb - 1) / wpb)), pblock(64 * wpb);
+#define GAT_PULL_LAUNCH(V2_)                                                                                                          \
+    do {                                                                                                                              \
+        if (n_heavy > 0) {                             /* long lists first: they are the longest-running waves */                      \
+            hipLaunchKernelGGL((gpl_pull_chunk_kernel<HD, N, BF, LASTD, V2_>), cgrid, dim3(256), 0, s, chunks, n_chunks, stash, cdst, gfull, hbits, \
+                               gh_stride, hb_stride, a, slope, part);                                                                  \
+            const int64_t threads = (int64_t)n_heavy * HD;                                                                              \
+            hipLaunchKernelGGL(gpl_heavy_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, heavy, n_heavy, part, gPL, HD); \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((gpl_pull_kernel<HD, N, BF, LASTD, V2_>), pgrid, pblock, 0, s, src_ptr, stash, cdst, gfull, hbits, gh_stride, hb_stride, \
+                           a, slope, gPL, n_table, heavy_slots(n_slots));                                                              \
+    } while (0)
     if constexpr (!BF) {
-        if (v2) hipLaunchKernelGGL((gpl_pull_kernel<HD, N, false, LASTD, true>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
-                                   cdst, gfull, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, heavy_slots(n_slots));
+        if (v2 == 1) GAT_PULL_LAUNCH(1);
+        else if (v2 == 2) GAT_PULL_LAUNCH(2);
+        else GAT_PULL_LAUNCH(0);
+    } else {
+        GAT_PULL_LAUNCH(0);
     }
-    if (!v2) hipLaunchKernelGGL((gpl_pull_kernel<HD, N, BF, LASTD>), dim3((unsigned)((n_table + wpb - 1) / wpb)), dim3(64 * wpb), 0, s, src_ptr, stash,
-                                cdst, gfull, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, heavy_slots(n_slots));
+#undef GAT_PULL_LAUNCH
     GAT_HIP(hipGetLastError());
     return 0;
 }
