@@ -510,13 +510,16 @@ __device__ __forceinline__ typename PullVec<N>::T pull_range2(const PullTabs<N>&
     const uint32_t doff = (uint32_t)(lane & (CH - 1)) * 4u;
     int dv = *reinterpret_cast<const int32_t*>(dp + doff);
     for (int rem = e - b; rem > 0; rem -= CH, sp += CH * LPE * 4, dp += CH * 4) {
-        const int dn = *reinterpret_cast<const int32_t*>(dp + CH * 4 + doff);          // next chunk (padding keeps it legal)
+        const int dn = *reinterpret_cast<const int32_t*>(dp + CH * 4 + doff);          // next chunk's destinations, unconditionally (padding)
         const int d0 = __builtin_amdgcn_readfirstlane(dv);                              // the chunk's first slot: always inside the list
         uint32_t w[U];
         V g[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool valid = u * G + gidx < rem;
+            // unclamped (the padding keeps it legal; a slot beyond the list reads the next source's record and is zeroed below).
+            // Redirecting such lanes to the chunk's first record instead cost the last layer's launch +1.1 ms (1.71 -> 2.79):
+            // the per-lane offset stops being loop-invariant
             const uint32_t ww = *reinterpret_cast<const uint32_t*>(sp + (uint32_t)((u * G + gidx) * LPE + cp) * 4u);
             int drow = __shfl(dv, u * G + gidx);
             drow = valid ? drow : d0;
@@ -740,10 +743,15 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
     }
     // second form of the slot walk (pull_range2): fp32 tables; the last-layer variant needs the 64-byte node records.
     // GAT_PULL_V2 = 0 first form | 1 second form, multipliers from LDS tables | 2 second form, multipliers by bit selects (A/B)
-    // Products shape, same box: 5.01 / 5.89 / 4.78 ms per step for 0 / 1 / 2 — the tables cost every 64-thread block its set-up
-    // and put an LDS round trip behind every record load; the bit selects are the default
-    static const int v2_env = [] { const char* e = getenv("GAT_PULL_V2"); return e ? atoi(e) : 2; }();
-    const int v2 = (!BF && (LASTD == 0 || (gh_stride == 16 && hb_stride == 64))) ? v2_env : 0;
+    // Per launch on the Products shape (rocprofv3, same box): first form 2.25 ms hidden layer / 1.95 ms last layer; second form
+    // with bit selects 2.45 / 1.71; with LDS tables slower on both (every 64-thread block pays the table set-up, and an LDS round
+    // trip sits behind every record load).  The last layer's walk is vector-ALU-bound (its rows are one cache line: 80-100 % VALU
+    // busy) and gains from the shorter instruction stream; the hidden layer's is bound by its two-line gathers and loses to the
+    // second form's unclamped chunk reads (+8 % record lines).  Default: second form for the last layer only; GAT_PULL_V2 forces
+    // one form on both (0 | 1 | 2).
+    static const int v2_env = [] { const char* e = getenv("GAT_PULL_V2"); return e ? atoi(e) : -1; }();
+    const int v2_want = v2_env >= 0 ? v2_env : (LASTD > 0 ? 2 : 0);
+    const int v2 = (!BF && (LASTD == 0 || (gh_stride == 16 && hb_stride == 64))) ? v2_want : 0;
     const dim3 cgrid((unsigned)((n_chunks + 3) / 4)), pgrid((unsigned)((n_table + wpb - 1) / wpb)), pblock(64 * wpb);
 #define GAT_PULL_LAUNCH(V2_)                                                                                                          \
     do {                                                                                                                              \
