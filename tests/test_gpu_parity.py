@@ -367,15 +367,17 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
                                  # the headline's last-layer variant (64-B gH / decision-byte records rebuilt by the pull pass): size-selected
                                  # on the Products shape only, so small tests force it — with both pull kernels, chunked heavy sources,
                                  # split rows and the wave-per-row backward
-                                 {"GAT_PULL_LAST": "1"}, {"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"},
-                                 {"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "0", "GAT_GPL_HEAVY": "16"}, {"GAT_PULL_LAST": "1", "GAT_ROWGROUP": "0"},
+                                 {"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"},
+                                 {"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "0", "GAT_GPL_HEAVY": "16", "GAT_ROWGROUP": "0"},
                                  # the wave-specialised record-store experiment kernels (measured, not the default)
                                  {"GAT_DBG": "4"}, {"GAT_DBG": "5", "GAT_PULL_LAST": "1"}, {"GAT_DBG": "6"},
-                                 # message rows from the group-per-row backward (config 5's kernel) at fp32 / H*D = 64 and 32, and its A/B
+                                 # message rows from the wave-per-row backward (config 5's round-2 kernel; the group-per-row one is the default
+                                 # of the GAT_BWD_STASH=0 settings above)
                                  {"GAT_BWD_STASH": "0", "GAT_GROUP_MSG": "0"},
-                                 # the forms of the pull pass's slot walk (gat_csc.hip pull_range / pull_range2), hidden-layer and last-layer variants
+                                 # the forms of the pull pass's slot walk (gat_csc.hip pull_range / pull_range2) forced on both layers; the
+                                 # default (second form for the last layer only) runs in the GAT_PULL_LAST=1 settings above
                                  {"GAT_PULL_V2": "0", "GAT_PULL_LAST": "1"}, {"GAT_PULL_V2": "1", "GAT_PULL_LAST": "1", "GAT_GPL_HEAVY": "16"},
-                                 {"GAT_PULL_V2": "2", "GAT_PULL_LAST": "1", "GAT_GPL_HEAVY": "16"}, {"GAT_PULL_V2": "2", "GAT_PULL_LAST": "0"}])
+                                 {"GAT_PULL_V2": "2", "GAT_PULL_LAST": "0", "GAT_GPL_HEAVY": "16"}])
 def test_ab_switches_stay_correct(pkg, orc, env):
     """The A/B switches of DESIGN §7 select other kernels / launch shapes for the SAME math: each must still
     match the oracle (they are read once per process, hence a subprocess)."""
