@@ -53,7 +53,7 @@ COMM_PIPELINE = 2
 (TAP_SRC, TAP_DST, TAP_ALPHA, TAP_HPRE, TAP_HOUT, TAP_Y, TAP_G, TAP_GE, TAP_MAX, TAP_SUM, TAP_PL,
  TAP_PR, TAP_SCORE, TAP_GALPHA, TAP_GX) = range(15)
 (K_PROJECT, K_EDGE_FWD, K_HEAD_FWD, K_HEAD_BWD, K_EDGE_BWD, K_GPL_SUM, K_GRAD_W, K_GRAD_X, K_MISC,
- K_EXCHANGE, K_COUNT) = range(11)
+ K_EXCHANGE, K_EDGE_FUSED, K_COUNT) = range(12)
 COMM_ID_BYTES = 128
 PATH_GENERIC_SHAPE, PATH_FAST, PATH_GENERIC_SIZE = 0, 1, 2
 

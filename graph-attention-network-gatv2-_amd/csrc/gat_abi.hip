@@ -727,8 +727,14 @@ int gat_layer_project(gat_ctx* c, int32_t l) {
     return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream);
 }
 
+static EdgeFwdArgs plan_forward_edges(gat_ctx* c, int32_t l);
 int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
     GAT_TRY(check_layer(c, l));
+    const EdgeFwdArgs a = plan_forward_edges(c, l);
+    Scope t(c, GAT_K_EDGE_FWD);
+    return launch_edge_forward(a, c->stream);
+}
+static EdgeFwdArgs plan_forward_edges(gat_ctx* c, int32_t l) {
     Layer& y = c->layers[l];
     EdgeFwdArgs a{};
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
@@ -737,8 +743,7 @@ int gat_layer_forward_edges(gat_ctx* c, int32_t l) {
     a.slope = c->cfg.negative_slope;
     a.items = c->items; a.n_items = c->work.n_items; a.slot_info = c->slot_info; a.n_slots = c->work.n_slots; a.n_split = c->work.n_split;
     a.part_acc = c->part_acc; a.part_mz = c->part_mz;
-    Scope t(c, GAT_K_EDGE_FWD);
-    return launch_edge_forward(a, c->stream);
+    return a;
 }
 
 int gat_head_forward(gat_ctx* c, float* loss_sum, int32_t* n_correct) {
@@ -776,15 +781,12 @@ int gat_head_backward(gat_ctx* c) {
     return launch_head_backward(a, c->stream);
 }
 
-int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
-    GAT_TRY(check_layer(c, l));
+// Arguments of layer l's edge backward (shared by gat_layer_backward_edges and the fused last layer of gat_step).
+struct BwdPlan { EdgeBwdArgs a; bool store, stash, last_g; };
+static int plan_backward_edges(gat_ctx* c, int32_t l, BwdPlan* P) {
     Layer& y = c->layers[l];
     const bool store = c->msg != nullptr && edge_fast_path(y.H, y.D, c->n_table);
     const bool stash = store && y.stash && c->stash != nullptr;
-    if (!store) {
-        Scope t(c, GAT_K_MISC);
-        GAT_HIP(hipMemsetAsync(c->gPL, 0, (size_t)c->n_table * y.HD * sizeof(float), c->stream));
-    }
     EdgeBwdArgs a{};
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
     a.alpha = y.alpha; a.mstat = y.mstat; a.zstat = y.zstat;
@@ -808,23 +810,42 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     a.ga_blocks = edge_fast_path(y.H, y.D, c->n_table) ? edge_backward_blocks(c->work.n_items, y.H, y.D, store, y.ge != nullptr, bf16(c), stash)
                                            : edge_backward_blocks(c->n_rows * 4, y.H, y.D, false, false, false);
     a.slope = c->cfg.negative_slope;
+    P->a = a; P->store = store; P->stash = stash; P->last_g = last_g;
+    return 0;
+}
+// The source-major pass of layer l (records -> gPL, or message rows -> gPL)
+static int sum_backward_edges(gat_ctx* c, int32_t l, const BwdPlan& P) {
+    Layer& y = c->layers[l];
+    if (P.stash) {
+        Scope t(c, GAT_K_GPL_SUM);
+        return launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, bf16(c), P.last_g ? c->gH : nullptr, P.last_g ? c->hbits : nullptr, c->gh_stride, 64,
+                               a_of(c, l), c->cfg.negative_slope, c->gPL, c->n_table,
+                               c->n_edges, y.H, y.D, c->gpl_chunks, c->n_gpl_chunks, c->gpl_heavy, c->n_gpl_heavy, c->gpl_part,
+                               c->pull_items, c->n_pull_items, c->stream);
+    }
+    if (P.store) {
+        Scope t(c, GAT_K_GPL_SUM);
+        return launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, bf16(c), c->gpl_chunks, c->n_gpl_chunks,
+                              c->gpl_heavy, c->n_gpl_heavy, c->gpl_part, c->stream);
+    }
+    return 0;
+}
+int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
+    GAT_TRY(check_layer(c, l));
+    Layer& y = c->layers[l];
+    BwdPlan P;
+    GAT_TRY(plan_backward_edges(c, l, &P));
+    if (!P.store) {
+        Scope t(c, GAT_K_MISC);
+        GAT_HIP(hipMemsetAsync(c->gPL, 0, (size_t)c->n_table * y.HD * sizeof(float), c->stream));
+    }
     {
         Scope t(c, GAT_K_EDGE_BWD);
-        GAT_TRY(launch_edge_backward(a, c->stream));
+        GAT_TRY(launch_edge_backward(P.a, c->stream));
     }
-    if (stash) {
-        Scope t(c, GAT_K_GPL_SUM);
-        GAT_TRY(launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, bf16(c), last_g ? c->gH : nullptr, last_g ? c->hbits : nullptr, c->gh_stride, 64,
-                                a_of(c, l), c->cfg.negative_slope, c->gPL, c->n_table,
-                                c->n_edges, y.H, y.D, c->gpl_chunks, c->n_gpl_chunks, c->gpl_heavy, c->n_gpl_heavy, c->gpl_part,
-                                c->pull_items, c->n_pull_items, c->stream));
-    } else if (store) {
-        Scope t(c, GAT_K_GPL_SUM);
-        GAT_TRY(launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, bf16(c), c->gpl_chunks, c->n_gpl_chunks,
-                               c->gpl_heavy, c->n_gpl_heavy, c->gpl_part, c->stream));
-    }
+    GAT_TRY(sum_backward_edges(c, l, P));
     Scope t(c, GAT_K_MISC);
-    return launch_reduce_partials_add(a.ga_partial, a.ga_blocks, y.HD, ga_of(c, l), c->stream);
+    return launch_reduce_partials_add(P.a.ga_partial, P.a.ga_blocks, y.HD, ga_of(c, l), c->stream);
 }
 
 int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
@@ -894,15 +915,18 @@ static int forward_exchange_pipelined(gat_ctx* c, int l) {
     GAT_HIP(hipStreamWaitEvent(c->stream, c->comm_events[K], 0));
     return 0;
 }
-static int forward_phases(gat_ctx* c) {
-    for (int l = 0; l < c->cfg.num_layers; ++l) {
+static int forward_phases(gat_ctx* c, int l_end = -1, bool last_edges = true) {
+    // layers [0, l_end) completely; last_edges = false: the last of them stops after its projection (+ exchange)
+    if (l_end < 0) l_end = c->cfg.num_layers;
+    for (int l = 0; l < l_end; ++l) {
+        const bool edges = last_edges || l < l_end - 1;
         // the chunked projection runs the streaming kernel; a layer whose one-launch projection takes the split-K kernel
         // (few rows, F > 128: another summation order) keeps the plain exchange, so that K chunks stay bitwise K = 1
         if (c->comm && needs_exchange(c, l) && c->comm_chunks > 1 &&
             project_scratch_floats(c->n_rows, c->layers[l].F, c->layers[l].HD, kPartBoth) == 0) {
             GAT_TRY(check_layer(c, l));
             GAT_TRY(forward_exchange_pipelined(c, l));
-            GAT_TRY(gat_layer_forward_edges(c, l));
+            if (edges) GAT_TRY(gat_layer_forward_edges(c, l));
             continue;
         }
         GAT_TRY(gat_layer_project(c, l));
@@ -910,7 +934,7 @@ static int forward_phases(gat_ctx* c) {
             Scope t(c, GAT_K_EXCHANGE);
             GAT_TRY(c->comm->all_gather(c->layers[l].PL, pl_slice(c, c->layers[l]), c->stream));
         }
-        GAT_TRY(gat_layer_forward_edges(c, l));
+        if (edges) GAT_TRY(gat_layer_forward_edges(c, l));
     }
     return 0;
 }
@@ -931,17 +955,76 @@ static bool fused_head(gat_ctx* c) {
     head_args(c, &f, &b);
     return head_step_supported(b);
 }
-static int head_step(gat_ctx* c) {
+static int head_step(gat_ctx* c, bool with_gh = true) {
     HeadArgs f{}; HeadBwdArgs b{};
     head_args(c, &f, &b);
+    if (!with_gh) b.gh_out = nullptr;               // loss, #correct and grad_Wo only (the fused last layer formed gH itself)
     Scope t(c, GAT_K_HEAD_BWD);
     c->y_valid = false;
     return launch_head_step(f, b, c->stream);
 }
-static int backward_phases(gat_ctx* c, bool head_done = false) {
+// gat_step: the last layer's forward edge pass, the output head and its backward edge pass fused per destination row
+// (edge_last_fused_kernel) — single shard, fp32, H*D = 64 / D = 8 record path.  The idea: the separate backward finds nothing
+// of the forward's rows left in the caches when a pass's gathers exceed the Infinity Cache; fused per row, the second walk of
+// a row's sources comes a few microseconds after the first.
+static bool fused_last(gat_ctx* c) {
+    if (!fused_head(c) || bf16(c) || c->comm || c->n_table != c->n_rows || c->cfg.flat_lrelu_index) return false;
+    const Layer& y = c->layers.back();
+    if (!edge_fast_path(y.H, y.D, c->n_table) || !y.stash || c->stash == nullptr || c->gH == nullptr) return false;
+    if (!edge_last_fused_supported(y.H, y.D, c->cfg.num_classes) || c->dbg != 0) return false;
+    // MEASURED, NOT THE DEFAULT (DESIGN §4 "Round 3"): on the Products shape the fused launch takes 5.0 ms for the 76 % of the edges
+    // that sit in unsplit rows — what the separate forward + backward take for them — and the split rows' segments, launched on
+    // their own, lose what they used to hide behind the bulk: 20.95 vs 20.78 ms per step.  GAT_FUSE_LAST=1 enables.
+    static const int env = [] { const char* e = getenv("GAT_FUSE_LAST"); return e ? (e[0] == '0' ? 0 : 1) : 0; }();
+    return env == 1;
+}
+static int last_layer_fused(gat_ctx* c) {
+    const int l = c->cfg.num_layers - 1;
+    Layer& y = c->layers[l];
+    BwdPlan P;
+    GAT_TRY(plan_backward_edges(c, l, &P));
+    const EdgeFwdArgs f = plan_forward_edges(c, l);
+    const int32_t n_seg = c->work.n_slots;          // the segments of split rows come first in the work list
+    float* ga_a = P.a.ga_partial;                   // this layer's region (2048 rows): the segments' launch, then the fused one,
+    int blocks_a = 0;                               // back to back — ONE reduction job (two jobs into one output would race)
+    if (n_seg > 0) {                                // split rows: forward segments + fix-up, their gH, backward segments + fix-up
+        EdgeFwdArgs fs = f;
+        fs.n_items = n_seg;
+        {
+            Scope t(c, GAT_K_EDGE_FWD);
+            GAT_TRY(launch_edge_forward(fs, c->stream));
+        }
+        {
+            Scope t(c, GAT_K_HEAD_BWD);
+            GAT_TRY(launch_head_rows(c->slot_info, c->work.n_slots, c->work.n_split, Wo_of(c), y.hout, c->labels_eff ? c->labels_eff : c->labels,
+                                     c->gH, c->gh_stride, c->cfg.num_classes, y.D, c->stream));
+        }
+        EdgeBwdArgs bs = P.a;
+        bs.n_items = n_seg;
+        bs.ga_partial = ga_a;
+        bs.ga_blocks = blocks_a = std::min(1024, edge_backward_blocks(n_seg, y.H, y.D, P.store, false, false, P.stash));
+        Scope t(c, GAT_K_EDGE_BWD);
+        GAT_TRY(launch_edge_backward(bs, c->stream));
+    }
+    EdgeLastArgs a{};
+    a.f = f; a.f.items = c->items + n_seg; a.f.n_items = c->work.n_items - n_seg;
+    float* ga_b = ga_a + (int64_t)blocks_a * y.HD;
+    a.b = P.a; a.b.ga_partial = ga_b; a.b.ga_blocks = a.f.n_items > 0 ? edge_last_fused_blocks(a.f.n_items) : 0;
+    a.Wo = Wo_of(c); a.labels = c->labels_eff ? c->labels_eff : c->labels; a.gh_out = c->gH; a.C = c->cfg.num_classes;
+    {
+        Scope t(c, GAT_K_EDGE_FUSED);
+        GAT_TRY(launch_edge_last_fused(a, c->stream));
+    }
+    GAT_TRY(head_step(c, false));                   // loss, #correct, grad_Wo from the stored H (all rows)
+    GAT_TRY(sum_backward_edges(c, l, P));
+    Scope t(c, GAT_K_MISC);
+    return launch_reduce_partials_add(ga_a, blocks_a + a.b.ga_blocks, y.HD, ga_of(c, l), c->stream);
+}
+static int backward_phases(gat_ctx* c, bool head_done = false, bool last_edges_done = false) {
+    // last_edges_done: the last layer's edge passes (incl. its source-major pass) have run already (fused last layer)
     if (!head_done) GAT_TRY(gat_head_backward(c));
     for (int l = c->cfg.num_layers - 1; l >= 0; --l) {
-        GAT_TRY(gat_layer_backward_edges(c, l));
+        if (!(last_edges_done && l == c->cfg.num_layers - 1)) GAT_TRY(gat_layer_backward_edges(c, l));
         if (c->comm && needs_exchange(c, l)) {
             Scope t(c, GAT_K_EXCHANGE);
             if (c->comm_gpl_bf16) GAT_TRY(c->comm->reduce_scatter_bf16(c->gPL, table_slice(c, c->layers[l]), c->stream));
@@ -1042,6 +1125,13 @@ static void graph_drop(gat_ctx* c) {
 }
 static int step_body(gat_ctx* c, float* host_tail = nullptr, bool* host_done = nullptr) {
     if (host_done) *host_done = false;
+    if (fused_last(c)) {
+        GAT_TRY(forward_phases(c, c->cfg.num_layers, false));      // every layer; the last one stops after its projection
+        BatchScope batch(c);
+        GAT_TRY(last_layer_fused(c));
+        GAT_TRY(backward_phases(c, true, true));
+        return batch.finish(c, true, host_tail, host_done);
+    }
     GAT_TRY(forward_phases(c));
     BatchScope batch(c);
     if (fused_head(c)) {
@@ -1419,7 +1509,7 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
 // ---- measurement -------------------------------------------------------------------------------------------------------
 static const char* kNames[GAT_K_COUNT] = {"project_gemm", "edge_forward", "head_forward", "head_backward",
                                           "edge_backward", "gpl_sum", "grad_w_gemm", "grad_x_gemm", "misc",
-                                          "exchange"};
+                                          "exchange", "edge_last_fused"};
 const char* gat_kernel_name(int k) { return (k >= 0 && k < GAT_K_COUNT) ? kNames[k] : "?"; }
 int gat_kernel_stats(gat_ctx* c, int k, int64_t* launches, double* total_ms) {
     if (!c || k < 0 || k >= GAT_K_COUNT) return fail(GAT_E_INVALID, "bad argument");
@@ -1471,7 +1561,17 @@ int gat_algorithmic_bytes_shape(const gat_config* cfg, int64_t n_rows, int64_t n
 }
 int gat_algorithmic_bytes(gat_ctx* c, double* bytes_step, double* per_kernel) {
     if (!c || !c->have_graph) return fail(GAT_E_STATE, "graph not set");
-    return gat_algorithmic_bytes_shape(&c->cfg, c->n_rows, c->n_edges, c->n_table, c->Xtab != nullptr, bytes_step, per_kernel);
+    GAT_TRY(gat_algorithmic_bytes_shape(&c->cfg, c->n_rows, c->n_edges, c->n_table, c->Xtab != nullptr, bytes_step, per_kernel));
+    if (per_kernel && c->buffers_ready && fused_last(c)) {
+        // gat_step runs the last layer's forward and backward edge passes (and forms gH) in ONE kernel class: its share of
+        // the SAME byte model moves there (the step total is unchanged; the head class keeps its bytes: head_step still runs)
+        const int L = c->cfg.num_layers;
+        const double N = (double)c->n_rows, E = (double)c->n_edges, H = c->layers[L - 1].H, D = c->layers[L - 1].D, HD = H * D;
+        const double fwd = 4 * (N + 1) + 4 * E + 4.0 * (E * HD + N * HD + E * H + N * HD + N * D);
+        const double bwd = 4 * (N + 1) + 4 * E + 4.0 * (N * HD + E * HD + N * HD + E * H + N * HD);
+        per_kernel[GAT_K_EDGE_FWD] -= fwd; per_kernel[GAT_K_EDGE_BWD] -= bwd; per_kernel[GAT_K_EDGE_FUSED] += fwd + bwd;
+    }
+    return 0;
 }
 
 }  // extern "C"

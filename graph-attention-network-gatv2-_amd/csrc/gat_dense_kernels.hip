@@ -436,9 +436,11 @@ __global__ __launch_bounds__(256) void head_step_kernel(HeadArgs F, HeadBwdArgs 
 #pragma unroll
                     for (int d = 0; d < DL; ++d) acc[d] += s_wo[c * DL + d] * z;
                 }
-                float* out = A.gh_out + (n0 + tid) * (A.gh_stride ? A.gh_stride : DL);
+                if (A.gh_out != nullptr) {                 // null: loss, #correct and grad_Wo only (fused last layer: gH formed there)
+                    float* out = A.gh_out + (n0 + tid) * (A.gh_stride ? A.gh_stride : DL);
 #pragma unroll
-                for (int d = 0; d < DL; ++d) out[d] = acc[d];
+                    for (int d = 0; d < DL; ++d) out[d] = acc[d];
+                }
             }
         } else if (whalf < 2) {
             const int r0 = whalf * 64, r1 = (r0 + 64 < rows_here) ? r0 + 64 : rows_here;
@@ -603,7 +605,9 @@ bool head_step_supported(const HeadBwdArgs& b) {
     return b.g == nullptr && b.gh_out != nullptr && b.C <= 64 && (b.DL == 4 || b.DL == 8 || b.DL == 16);
 }
 int launch_head_step(const HeadArgs& f, const HeadBwdArgs& b, hipStream_t s) {
-    if (!head_step_supported(b)) return fail(GAT_E_UNSUPPORTED, "head_step: shape outside the fused kernel");
+    HeadBwdArgs probe = b;
+    if (probe.gh_out == nullptr) probe.gh_out = reinterpret_cast<float*>(1);       // the gH output is optional here
+    if (!head_step_supported(probe)) return fail(GAT_E_UNSUPPORTED, "head_step: shape outside the fused kernel");
     const int ldz = (b.C % 2 == 0) ? b.C + 1 : b.C;
     const size_t lds = ((size_t)b.C * b.DL + (size_t)128 * (ldz + b.DL)) * sizeof(float);
     int blocks = std::min(head_blocks(b.n_rows), head_bwd_blocks(b.n_rows, b.C, b.DL));      // both partial buffers

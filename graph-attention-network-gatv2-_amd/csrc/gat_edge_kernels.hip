@@ -1032,6 +1032,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
         vnf<N> gpr = vzero<N>();
         const int nst = wave_max_over_groups<HD, N>((e - b + U - 1) / U);
+        if constexpr (DBG == 9) {
+            // Timing experiment (results unchanged): walk the row's source rows ONCE MORE before the real walk, as a forward pass
+            // fused into this kernel would — does the second gather of a row, a few microseconds after the first, come out of
+            // the L2 / Infinity Cache fast enough to pay for fusing the last layer's forward, head and backward per row?
+            float dummy = 0.f;
+            int j0 = b + (cp & (U - 1));
+            j0 = j0 < e ? j0 : e - 1;
+            int sv = A.col_idx[j0 > 0 ? j0 : 0];
+            for (int st = 0; st < nst; ++st) {
+                int jn = b + (st + 1) * U + (cp & (U - 1));
+                jn = jn < e ? jn : e - 1;
+                const int sn = A.col_idx[jn > 0 ? jn : 0];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const vnf<N> vv = gather_row_n<HD, N, BF>(A.PL, __shfl(sv, gidx * LPE + u), cp);
+                    dummy += hsum<N>(vv);
+                }
+                sv = sn;
+            }
+            if (dummy == 12345.6789f) gpr[0] += 1.0f;          // never true in practice: keeps the walk alive
+        }
         // Software pipeline.  vmcnt retires loads AND stores in issue order, so a store issued ahead of a gather makes the
         // gather's consumer wait for the store's acknowledgement as well (measured: without its record stores the kernel
         // ran 2x faster, wherever the stores went).  Per step, in this order: gathers of the step; the PREVIOUS step's
@@ -1113,6 +1134,268 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (threadIdx.x < HD)
         A.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LAST LAYER, FUSED PER ROW (gat_step, H*D = 64, D = 8, fp32): forward edge pass, output head and backward edge pass of a
+// destination row in ONE kernel.  For the last layer the whole chain is row-local — h_pre[d] -> H[d] (mean over heads, E:440-449)
+// -> z, y, dz of node d (E:463-512, 571-573) -> gH[d] = Wo^T dz -> g[d] = gH * LReLU'(h_pre) / H (E:598-603) -> the row's
+// alpha, grad_attn_coeff, grad_attn_score, records, gPR, grad_a terms — so the row's source rows PL[src] can be walked twice
+// within a few microseconds: the second walk is served by the L2 / the 256 MiB Infinity Cache instead of HBM (measured with
+// GAT_DBG=9: a second walk inside the backward costs 1.35 ms per launch, the stand-alone forward 2.37).  Body = edge_fwd3_kernel's
+// walk, a 16-lane head (classes cp, cp+16, ...; W_o in LDS), edge_bwd3_kernel's walk; same arithmetic per row as those kernels.
+// Whole rows only: the segments of split (hub) rows keep the three-kernel path.  Loss, #correct and grad_Wo come from
+// head_step_kernel on the stored H (as before, without its gH output).
+template <int HD, int D, int N>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void edge_last_fused_kernel(EdgeLastArgs A) {
+    constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;
+    constexpr int U = 4, JC = 4;                         // JC * LPE >= the 64 classes W_o may have here
+    static_assert(LPE == 16 && DL == 2 && D == 8 && N == 4, "16 lanes per row, two lanes per head, D = 8");
+    __shared__ float red[4][HD];
+    __shared__ float s_wo[64 * D];
+    const EdgeFwdArgs& F = A.f;
+    const EdgeBwdArgs& B = A.b;
+    const int C = A.C;
+    for (int i = threadIdx.x; i < C * D; i += blockDim.x) s_wo[i] = A.Wo[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cp = lane % LPE, gidx = lane / LPE;
+    const int c = N * cp;
+    const vnf<N> ac = *reinterpret_cast<const vnf<N>*>(F.a + c);
+    const vnf<N> acs = ac * F.slope;
+    const vnf<N> ac2 = ac * kLog2e;
+    const int64_t nquads = (F.n_items + G - 1) / G;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    vnf<N> ga = vzero<N>();
+
+    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < nquads; q += nwaves) {
+        const int64_t it = q * G + gidx;
+        int row = -1, b = 0, e = 0;                   // group without an item: walks nothing, writes nothing
+        if (it < F.n_items) { const int4 item = F.items[it]; row = item.x; b = item.y; e = item.z; }
+        const int64_t rowc = row < 0 ? 0 : row;
+        const int nst = wave_max_over_groups<HD, N>((e - b + U - 1) / U);
+        const vnf<N> pr = *reinterpret_cast<const vnf<N>*>(F.PR + rowc * HD + c);
+        // ---- forward walk (edge_fwd3_kernel) ----
+        float m = -1e9f * kLog2e, Z = 0.f;
+        vnf<N> acc = vzero<N>();
+        {
+            auto load_src = [&](int st) {
+                int j = b + st * U + (cp & (U - 1));
+                j = j < e ? j : e - 1;
+                return F.col_idx[j > 0 ? j : 0];
+            };
+            int srcv = load_src(0);
+            for (int st = 0; st < nst; ++st) {
+                const int srcn = load_src(st + 1);
+                vnf<N> v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = gather_row_n<HD, N, false>(F.PL, __shfl(srcv, gidx * LPE + u), cp);
+                float t[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[u] = hsum<N>(ac2 * lrelu_n<N>(v[u] + pr, F.slope));
+                group_sum_n<DL, U>(t);
+                float cm = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    t[u] = (b + st * U + u < e) ? t[u] : -INFINITY;
+                    cm = fmaxf(cm, t[u]);
+                }
+                const float mn = fmaxf(m, cm);
+                const float scale = exp2_fast(m - mn);
+                Z *= scale;
+                acc = acc * scale;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float p = exp2_fast(t[u] - mn);
+                    Z += p;
+                    acc += p * v[u];
+                }
+                m = mn;
+                srcv = srcn;
+            }
+        }
+        const float inv = __builtin_amdgcn_rcpf(Z + 1e-8f);       // E:379 epsilon
+        const vnf<N> hp = acc * inv;
+        if (row >= 0) {
+            stream_store(reinterpret_cast<vnf<N>*>(F.hpre + rowc * HD + c), hp);
+            if ((c % D) == 0) { F.mstat[rowc * H + c / D] = m; F.zstat[rowc * H + c / D] = Z; }
+        }
+        // H[d] = mean over heads of LReLU(h_pre) (E:440-449): lanes of equal parity hold the same four dims afterwards
+        vnf<N> hm = lrelu_n<N>(hp, F.slope);
+#pragma unroll
+        for (int off = DL; off < LPE; off <<= 1) hm += shfl_xor_n<N>(hm, off);
+        hm = hm / (float)H;
+        if (row >= 0 && cp < DL) *reinterpret_cast<vnf<N>*>(F.hout + rowc * D + c) = hm;
+        const vnf<N> ho_other = shfl_xor_n<N>(hm, 1);
+        float ho[D];
+#pragma unroll
+        for (int k = 0; k < N; ++k) { ho[k] = (cp & 1) ? ho_other[k] : hm[k]; ho[N + k] = (cp & 1) ? hm[k] : ho_other[k]; }
+        // ---- output head of this node (E:463-512), its dz (E:571-573) and gH = Wo^T dz: classes cp, cp + 16, ... ----
+        const int lab = A.labels[rowc];                  // < 0: outside the training mask (gat_set_train_mask): dz = 0
+        float z[JC], mv = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int cls = cp + LPE * j;
+            z[j] = -INFINITY;
+            if (cls < C) {
+                float t = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) t += s_wo[cls * D + d] * ho[d];
+                z[j] = t;
+                mv = fmaxf(mv, t);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < LPE; off <<= 1) mv = fmaxf(mv, __shfl_xor(mv, off));
+        float ev[JC], sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < JC; ++j) { ev[j] = (cp + LPE * j < C) ? exp2_fast((z[j] - mv) * kLog2e) : 0.f; sum += ev[j]; }
+        sum = group_sum<LPE>(sum);
+        const float rden = 1.0f / (sum + 1e-8f);
+        float gh[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) gh[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < JC; ++j) {
+            const int cls = cp + LPE * j;
+            if (cls < C) {
+                const float dz = lab >= 0 ? ev[j] * rden - (cls == lab ? 1.0f : 0.0f) : 0.0f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) gh[d] += s_wo[cls * D + d] * dz;
+            }
+        }
+        group_sum_n<LPE, D>(gh);
+        vnf<N> ghl;                                      // the lane's four dims of gH
+#pragma unroll
+        for (int k = 0; k < N; ++k) ghl[k] = (cp & 1) ? gh[N + k] : gh[k];
+        if (row >= 0 && cp < DL) *reinterpret_cast<vnf<N>*>(A.gh_out + rowc * B.gh_stride + c) = ghl;   // the pull pass's node record
+        vnf<N> dsel;
+#pragma unroll
+        for (int i = 0; i < N; ++i) dsel[i] = hp[i] > 0.f ? 1.0f : F.slope;
+        const vnf<N> g = ghl * dsel * (1.0f / (float)H);                                                    // E:598-603
+        if (row >= 0) {
+            if (B.hbits != nullptr) {
+                uint32_t nib = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) nib |= (hp[i] > 0.f ? 1u : 0u) << i;
+                B.hbits[rowc * B.hb_stride + cp] = (uint8_t)nib;
+            } else {
+                stream_store(reinterpret_cast<vnf<N>*>(B.gfull + rowc * HD + c), g);
+            }
+        }
+        // ---- backward walk (edge_bwd3_kernel) ----
+        const float dot = group_sum<DL>(hsum<N>(g * hp));
+        const float m2 = m;
+        auto load_idx = [&](int st, int& srcv, int& posv) {
+            int j = b + st * U + (cp & (U - 1));
+            j = j < e ? j : e - 1;
+            j = j > 0 ? j : 0;
+            srcv = B.col_idx[j];
+            posv = B.pos[j];
+        };
+        auto spread = [&](int st, int srcv, int posv, int (&src)[U], uint32_t (&sl)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                src[u] = __shfl(srcv, gidx * LPE + u);
+                const uint32_t p = (uint32_t)__shfl(posv, gidx * LPE + u);
+                sl[u] = (b + st * U + u < e) ? p : B.stash_spare;
+            }
+        };
+        int srcv, posv, srcn, posn;
+        load_idx(0, srcv, posv);
+        load_idx(1, srcn, posn);
+        vnf<N> gpr = vzero<N>();
+        int src[U];
+        uint32_t sl[U], pend_s[U], pend_w[U];
+        spread(0, srcv, posv, src, sl);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { pend_w[u] = 0u; pend_s[u] = B.stash_spare; }
+        for (int st = 0; st < nst; ++st) {
+            vnf<N> v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = gather_row_n<HD, N, false>(B.PL, src[u], cp);
+#pragma unroll
+            for (int u = 0; u < U; ++u) stream_store(&B.stash[(uint64_t)pend_s[u] * LPE + cp], pend_w[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) pend_s[u] = sl[u];
+            spread(st + 1, srcn, posn, src, sl);
+            load_idx(st + 2, srcn, posn);
+            float al[U], ga_[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) al[u] = hsum<N>(ac2 * lrelu_n<N>(v[u] + pr, F.slope));
+            group_sum_n<DL, U>(al);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                al[u] = exp2_fast(al[u] - m2) * inv;
+                ga_[u] = hsum<N>(g * v[u]);
+            }
+            group_sum_n<DL, U>(ga_);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool valid = b + st * U + u < e;
+                const float ge = valid ? al[u] * (ga_[u] - dot) : 0.f;
+                const vnf<N> s = v[u] + pr;
+                const vnf<N> gs = ge * select_pos<N>(s, ac, acs);
+                ga += ge * lrelu_n<N>(s, F.slope);
+                gpr += gs;
+                uint32_t bits = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) bits |= (s[i] > 0.f ? 1u : 0u) << i;
+                const uint32_t w = __builtin_bit_cast(uint32_t, (cp & 1) ? ge : al[u]);
+                pend_w[u] = ((w + (1u << (N - 1))) & ~((1u << N) - 1u)) | bits;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) stream_store(&B.stash[(uint64_t)pend_s[u] * LPE + cp], pend_w[u]);
+        if (row >= 0) stream_store(reinterpret_cast<vnf<N>*>(B.gPR + rowc * HD + c), gpr);
+    }
+#pragma unroll
+    for (int off = LPE; off < 64; off <<= 1) ga += shfl_xor_n<N>(ga, off);
+    if (gidx == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[wave][c + i] = ga[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < HD)
+        B.ga_partial[(int64_t)blockIdx.x * HD + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// gH = Wo^T dz (and nothing else) of the SPLIT rows, whose forward runs as segments + fix-up: one thread per split row, the
+// head kernels' arithmetic (E:463-512, 571-573)
+__global__ __launch_bounds__(256) void head_rows_kernel(const int4* __restrict__ slot_info, int32_t n_slots, int32_t n_split,
+                                                       const float* __restrict__ Wo, const float* __restrict__ HL,
+                                                       const int32_t* __restrict__ labels, float* __restrict__ gh_out,
+                                                       int32_t gh_stride, int32_t C, int32_t DLAST) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_split) return;
+    const int64_t row = slot_info[slot_info[n_slots + k].x].x;
+    const float* x = HL + row * DLAST;
+    const int lab = labels[row];
+    float mv = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+        float t = 0.f;
+        for (int d = 0; d < DLAST; ++d) t += Wo[c * DLAST + d] * x[d];
+        mv = fmaxf(mv, t);
+    }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float t = 0.f;
+        for (int d = 0; d < DLAST; ++d) t += Wo[c * DLAST + d] * x[d];
+        sum += exp2_fast((t - mv) * kLog2e);
+    }
+    const double rden = 1.0 / ((double)sum + 1e-8);
+    float acc[16];
+    for (int d = 0; d < DLAST; ++d) acc[d] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float t = 0.f;
+        for (int d = 0; d < DLAST; ++d) t += Wo[c * DLAST + d] * x[d];
+        const float y = (float)((double)exp2_fast((t - mv) * kLog2e) * rden);
+        const float dz = lab >= 0 ? y - (c == lab ? 1.0f : 0.0f) : 0.0f;
+        for (int d = 0; d < DLAST; ++d) acc[d] += Wo[c * DLAST + d] * dz;
+    }
+    for (int d = 0; d < DLAST; ++d) gh_out[row * gh_stride + d] = acc[d];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1594,7 +1877,8 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
             if (a.gfull == nullptr || a.pos == nullptr) return fail(GAT_E_INVALID, "edge_backward: stash path needs gfull and pos");
             bool dbg_done = false;
             if constexpr (HD == 64 && D == 8) {      // timing experiments (GAT_DBG=1: no record store, 2: records in CSR order)
-                if (a.dbg == 4 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<7, 4>), grid, dim3(512), 0, s, a); dbg_done = true; }   // wave-specialised stores: 7 + 1 waves
+                if (a.dbg == 9 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 9>), grid, block, 0, s, a); dbg_done = true; }   // double walk
+                else if (a.dbg == 4 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<7, 4>), grid, dim3(512), 0, s, a); dbg_done = true; }   // wave-specialised stores: 7 + 1 waves
                 else if (a.dbg == 6 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4, 1>), grid, dim3(256), 0, s, a); dbg_done = true; }   // 3 + 1 waves, sc1 stores
                 else if (a.dbg == 7 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4, 2>), grid, dim3(256), 0, s, a); dbg_done = true; }   // sc0 sc1
                 else if (a.dbg == 8 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4, 3>), grid, dim3(256), 0, s, a); dbg_done = true; }   // nt
@@ -1742,6 +2026,32 @@ int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(3 * a.H + 2 * HD) * sizeof(float);
     if (lds > 64 * 1024) return fail(GAT_E_UNSUPPORTED, "edge_backward: H*D too large for the generic path");
     hipLaunchKernelGGL(edge_bwd_generic, dim3((unsigned)a.ga_blocks), dim3(64), lds, s, a);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+
+bool edge_last_fused_supported(int32_t H, int32_t D, int32_t C) { return H * D == 64 && D == 8 && C >= 1 && C <= 64; }
+int edge_last_fused_blocks(int64_t n_items) {
+    const int64_t want = std::max<int64_t>(1, ((n_items + 3) / 4 + 3) / 4);        // 4 rows per wave, 4 waves per block
+    const int cap = resident_blocks((const void*)edge_last_fused_kernel<64, 8, 4>);
+    return (int)std::min<int64_t>(want, cap);
+}
+int launch_edge_last_fused(const EdgeLastArgs& a, hipStream_t s) {
+    if (!edge_last_fused_supported(a.f.H, a.f.D, a.C)) return fail(GAT_E_UNSUPPORTED, "edge_last_fused: shape outside the kernel");
+    if (a.f.n_items <= 0) return 0;
+    if (a.f.items == nullptr || a.b.pos == nullptr || a.b.stash == nullptr || a.gh_out == nullptr || a.b.ga_blocks < 1 ||
+        (a.b.hbits == nullptr && a.b.gfull == nullptr))
+        return fail(GAT_E_INVALID, "edge_last_fused: missing buffers");
+    hipLaunchKernelGGL((edge_last_fused_kernel<64, 8, 4>), dim3((unsigned)a.b.ga_blocks), dim3(256), 0, s, a);
+    GAT_HIP(hipGetLastError());
+    return 0;
+}
+int launch_head_rows(const int4* slot_info, int32_t n_slots, int32_t n_split, const float* Wo, const float* HL, const int32_t* labels,
+                     float* gh_out, int32_t gh_stride, int32_t C, int32_t DLAST, hipStream_t s) {
+    if (n_split <= 0) return 0;
+    if (DLAST > 16) return fail(GAT_E_UNSUPPORTED, "head_rows: D_last > 16");
+    hipLaunchKernelGGL(head_rows_kernel, dim3((unsigned)((n_split + 255) / 256)), dim3(256), 0, s, slot_info, n_slots, n_split, Wo, HL,
+                       labels, gh_out, gh_stride, C, DLAST);
     GAT_HIP(hipGetLastError());
     return 0;
 }

@@ -117,6 +117,23 @@ struct EdgeBwdArgs {
     int32_t dbg;
 };
 int launch_edge_backward(const EdgeBwdArgs& a, hipStream_t s);
+// Last layer, fused per row (gat_step): forward edge pass + output head + backward edge pass of every WHOLE row in one kernel
+// (edge_last_fused_kernel); f / b as for the separate passes (f.items / f.n_items: the whole-row items only; b.ga_partial /
+// b.ga_blocks from edge_last_fused_blocks), gh_out = the [n_rows][gh_stride] node records the pull pass reads.
+struct EdgeLastArgs {
+    EdgeFwdArgs f;
+    EdgeBwdArgs b;
+    const float* Wo;          // [C][D]
+    const int32_t* labels;    // [n_rows]; negative = outside the training mask
+    float* gh_out;            // [n_rows][b.gh_stride]
+    int32_t C;
+};
+bool edge_last_fused_supported(int32_t H, int32_t D, int32_t C);
+int edge_last_fused_blocks(int64_t n_items);
+int launch_edge_last_fused(const EdgeLastArgs& a, hipStream_t s);
+// gH = Wo^T dz of the split rows only (their forward runs as segments): slot_info as in EdgeFwdArgs
+int launch_head_rows(const int4* slot_info, int32_t n_slots, int32_t n_split, const float* Wo, const float* HL, const int32_t* labels,
+                     float* gh_out, int32_t gh_stride, int32_t C, int32_t DLAST, hipStream_t s);
 // Words per edge record of the stash path for an (H, D) layer, 0 = that shape has no stash path (the message-row
 // path is used): two lanes per head are needed (D = 8 with four channels per lane, D = 4 with two).
 int edge_stash_words(int32_t H, int32_t D);

@@ -88,6 +88,7 @@ def _run(env, seed, cases, tag):
 @pytest.mark.parametrize("env,tag", [({}, ""), ({"GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"}, " groups, tiny segments"),
                                      ({"GAT_PULL_GROUPS": "0", "GAT_PULL_LAST": "0"}, " waves"), ({"GAT_ROWGROUP": "0"}, " chunked"),
                                      ({"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"}, " last-layer records, groups"),
-                                     ({"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "0", "GAT_ROWGROUP": "0"}, " last-layer records, waves, chunked")])
+                                     ({"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "0", "GAT_ROWGROUP": "0"}, " last-layer records, waves, chunked"),
+                                     ({"GAT_FUSE_LAST": "1", "GAT_PULL_LAST": "1"}, " last layer fused per row")])
 def test_random_small_cases(env, tag):
     _run(env, 20260 + len(tag), 6, tag)

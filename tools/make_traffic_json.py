@@ -10,7 +10,7 @@ writes = 64*TCC_EA0_WRREQ_64B + 32*(WRREQ - WRREQ_64B)
 """
 import collections, csv, glob, json, re, sys
 
-CLASSES = [("edge_bwd", "edge_backward"), ("edge_fwd", "edge_forward"), ("gpl_", "gpl_sum"),
+CLASSES = [("edge_last_fused", "edge_last_fused"), ("edge_bwd", "edge_backward"), ("edge_fwd", "edge_forward"), ("gpl_", "gpl_sum"),
            ("gradw_kernel", "grad_w_gemm"), ("gradw_x3_kernel", "grad_w_gemm"), ("EpiProject", "project_gemm"), ("EpiGradX", "grad_x_gemm"),
            ("EpiStore", "grad_x_gemm"), ("head_forward_kernel", "head_forward"), ("head_backward_kernel", "head_backward"),
            ("head_step_kernel", "head_backward")]
