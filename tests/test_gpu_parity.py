@@ -378,10 +378,9 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
                                  # default (second form for the last layer only) runs in the GAT_PULL_LAST=1 settings above
                                  {"GAT_PULL_V2": "0", "GAT_PULL_LAST": "1"}, {"GAT_PULL_V2": "1", "GAT_PULL_LAST": "1", "GAT_GPL_HEAVY": "16"},
                                  {"GAT_PULL_V2": "2", "GAT_PULL_LAST": "0", "GAT_GPL_HEAVY": "16"},
-                                 # the last layer fused per row (edge_last_fused_kernel; size-selected on the Products shape only), with the
+                                 # the last layer fused per row (edge_last_fused_kernel: measured, off by default — DESIGN §4 "Round 3"), with the
                                  # gfull and the node-record variants of what it leaves for the pull pass, many split rows (16-edge segments)
-                                 {"GAT_FUSE_LAST": "1"}, {"GAT_FUSE_LAST": "1", "GAT_PULL_LAST": "1", "GAT_SEG_EDGES": "16"},
-                                 {"GAT_FUSE_LAST": "0"}])
+                                 {"GAT_FUSE_LAST": "1"}, {"GAT_FUSE_LAST": "1", "GAT_PULL_LAST": "1", "GAT_SEG_EDGES": "16"}])
 def test_ab_switches_stay_correct(pkg, orc, env):
     """The A/B switches of DESIGN §7 select other kernels / launch shapes for the SAME math: each must still
     match the oracle (they are read once per process, hence a subprocess)."""
