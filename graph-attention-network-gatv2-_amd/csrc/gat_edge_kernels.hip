@@ -1146,6 +1146,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // walk, a 16-lane head (classes cp, cp+16, ...; W_o in LDS), edge_bwd3_kernel's walk; same arithmetic per row as those kernels.
 // Whole rows only: the segments of split (hub) rows keep the three-kernel path.  Loss, #correct and grad_Wo come from
 // head_step_kernel on the stored H (as before, without its gH output).
+// MEASURED, NOT THE DEFAULT (GAT_FUSE_LAST=1 enables; DESIGN §4 "Round 3"): at the backward's 4 waves per SIMD and with the head in
+// the middle, the fused launch takes as long as the separate passes for the rows it covers (5.03 ms for 76 % of the Products
+// shape's edges), and the split rows' launches lose the cover of the bulk: 20.95 vs 20.78 ms per step.  Parity-tested.
 template <int HD, int D, int N>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void edge_last_fused_kernel(EdgeLastArgs A) {
     constexpr int LPE = HD / N, G = 64 / LPE, DL = D / N, H = HD / D;

@@ -337,9 +337,10 @@ enum {
     GAT_K_PROJECT = 0, GAT_K_EDGE_FWD = 1, GAT_K_HEAD_FWD = 2, GAT_K_HEAD_BWD = 3,
     GAT_K_EDGE_BWD = 4, GAT_K_GPL_SUM = 5, GAT_K_GRAD_W = 6, GAT_K_GRAD_X = 7, GAT_K_MISC = 8,
     GAT_K_EXCHANGE = 9,     /* transport calls of gat_forward / gat_backward / gat_step (event-timed like kernels) */
-    GAT_K_EDGE_FUSED = 10,  /* gat_step on large single-shard fp32 graphs: the last layer's forward edge pass, the gH part of the
-                               head and its backward edge pass fused per destination row (E:1386-1428 + 1468 + 1489-1533 of
-                               that layer in one launch; gat_algorithmic_bytes moves that layer's edge bytes to this class) */
+    GAT_K_EDGE_FUSED = 10,  /* experiment, off unless GAT_FUSE_LAST=1 (measured not ahead: DESIGN §4): gat_step with the last layer's
+                               forward edge pass, the gH part of the head and its backward edge pass fused per destination row
+                               (E:1386-1428 + 1468 + 1489-1533 of that layer in one launch; gat_algorithmic_bytes then moves
+                               that layer's edge bytes to this class) */
     GAT_K_COUNT = 11
 };
 /* Accumulated HIP-event time of kernel class `k` since the last gat_kernel_stats_reset (needs
