@@ -998,7 +998,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 src[u] = __shfl(srcv, gidx * LPE + u);
-                const uint32_t p = (uint32_t)__shfl(posv, gidx * LPE + u);
+                uint32_t p = (uint32_t)__shfl(posv, gidx * LPE + u);
+                // timing experiments (wrong results): the same scattered stores folded into a window of 2^26 / 2^24 / 2^22 / 2^20 bytes
+                // — is it the SPAN of the scatter (address translation reach, DRAM page locality) that costs, or the scatter as such?
+                if constexpr (DBG == 10) p &= (1u << 20) - 1u;
+                if constexpr (DBG == 11) p &= (1u << 18) - 1u;
+                if constexpr (DBG == 12) p &= (1u << 16) - 1u;
+                if constexpr (DBG == 13) p &= (1u << 14) - 1u;
+                if constexpr (DBG == 14) p &= (1u << 24) - 1u;
                 sl[u] = (b + st * U + u < e) ? p : A.stash_spare;    // padded lanes store to the spare record (no exec-masked store)
             }
         };
@@ -1881,6 +1888,11 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
             bool dbg_done = false;
             if constexpr (HD == 64 && D == 8) {      // timing experiments (GAT_DBG=1: no record store, 2: records in CSR order)
                 if (a.dbg == 9 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 9>), grid, block, 0, s, a); dbg_done = true; }   // double walk
+                else if (a.dbg == 10 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 10>), grid, block, 0, s, a); dbg_done = true; }   // scatter folded into 64 MiB
+                else if (a.dbg == 11 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 11>), grid, block, 0, s, a); dbg_done = true; }   // 16 MiB
+                else if (a.dbg == 12 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 12>), grid, block, 0, s, a); dbg_done = true; }   // 4 MiB
+                else if (a.dbg == 13 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 13>), grid, block, 0, s, a); dbg_done = true; }   // 1 MiB
+                else if (a.dbg == 14 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 14>), grid, block, 0, s, a); dbg_done = true; }   // 1 GiB
                 else if (a.dbg == 4 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<7, 4>), grid, dim3(512), 0, s, a); dbg_done = true; }   // wave-specialised stores: 7 + 1 waves
                 else if (a.dbg == 6 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4, 1>), grid, dim3(256), 0, s, a); dbg_done = true; }   // 3 + 1 waves, sc1 stores
                 else if (a.dbg == 7 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4, 2>), grid, dim3(256), 0, s, a); dbg_done = true; }   // sc0 sc1
