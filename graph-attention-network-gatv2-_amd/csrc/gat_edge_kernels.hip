@@ -993,6 +993,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             j = j > 0 ? j : 0;
             srcv = A.col_idx[j];
             posv = (DBG == 2) ? j : A.pos[j];
+            // timing experiments (wrong results): K write FRONTS, each advancing sequentially with the CSR index — the store pattern of
+            // records laid out by (source block, CSR index): front = slot mod K (a pseudo-random block), place = front * E/K + j / K
+            if constexpr (DBG >= 15 && DBG <= 18) {
+                constexpr uint32_t K = DBG == 15 ? 64u : DBG == 16 ? 512u : DBG == 17 ? 4096u : 32768u;
+                const uint32_t per = A.stash_spare / K;
+                posv = (int)(((uint32_t)posv % K) * per + (uint32_t)j / K);
+            }
         };
         auto spread = [&](int st, int srcv, int posv, int (&src)[U], uint32_t (&sl)[U]) {
 #pragma unroll
@@ -1892,6 +1899,10 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
                 else if (a.dbg == 11 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 11>), grid, block, 0, s, a); dbg_done = true; }   // 16 MiB
                 else if (a.dbg == 12 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 12>), grid, block, 0, s, a); dbg_done = true; }   // 4 MiB
                 else if (a.dbg == 13 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 13>), grid, block, 0, s, a); dbg_done = true; }   // 1 MiB
+                else if (a.dbg == 15 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 15>), grid, block, 0, s, a); dbg_done = true; }   // 64 sequential write fronts
+                else if (a.dbg == 16 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 16>), grid, block, 0, s, a); dbg_done = true; }   // 512
+                else if (a.dbg == 17 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 17>), grid, block, 0, s, a); dbg_done = true; }   // 4,096
+                else if (a.dbg == 18 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 18>), grid, block, 0, s, a); dbg_done = true; }   // 32,768
                 else if (a.dbg == 14 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 14>), grid, block, 0, s, a); dbg_done = true; }   // 1 GiB
                 else if (a.dbg == 4 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<7, 4>), grid, dim3(512), 0, s, a); dbg_done = true; }   // wave-specialised stores: 7 + 1 waves
                 else if (a.dbg == 6 && row_groups()) { hipLaunchKernelGGL((edge_bwd4_kernel<3, 4, 1>), grid, dim3(256), 0, s, a); dbg_done = true; }   // 3 + 1 waves, sc1 stores
