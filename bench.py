@@ -66,6 +66,9 @@ def parse():
                     help="N>1, --comm native: remote gPL partial sums travel as bf16 (GAT_COMM_GPL_BF16; 1e-2 parity mode, NOT the headline).  "
                          "UNVERIFIED over RCCL beyond world 1 (only its host-transport twin is tested at 3 ranks): default off")
     ap.add_argument("--beta", type=float, default=0.75, help="power-law exponent of the degree law (debug)")
+    ap.add_argument("--sorted-sources", action="store_true",
+                    help="experiment, NOT the benchmark graph: source popularity decreasing with the node id (hot table rows adjacent) — "
+                         "what a popularity ordering of the table rows inside the library would buy (DESIGN 4, config 5)")
     return ap.parse_args()
 
 
@@ -215,7 +218,7 @@ def main():
     # generated ON the device (csrc/gat_synth.hip; bit-for-bit the host generator's arrays): the host only builds the
     # N-sized tables.  N > 1: every rank draws the whole graph on its own GPU and keeps its destination range.
     t_gen = time.perf_counter()
-    dsd = pkg.synth.make_dataset_device(args.workload, dev, scale=args.scale, beta=args.beta)
+    dsd = pkg.synth.make_dataset_device(args.workload, dev, scale=args.scale, beta=args.beta, sorted_sources=args.sorted_sources)
     row_ptr = dsd["row_ptr"]
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
@@ -361,7 +364,7 @@ def main():
                                 + (", remote gPL partials as bf16" if args.gpl_bf16 else ""))
                                if runner is not None else "single GPU",
                 "loss_per_node": loss / n, "setup_s": round(t_gen, 1), "index_s": round(t_up, 2),
-                "generator": "device (csrc/gat_synth.hip), bit-for-bit synth.py",
+                "generator": "device (csrc/gat_synth.hip), bit-for-bit synth.py" + (" — EXPERIMENT: sources sorted by popularity" if args.sorted_sources else ""),
             },
             "step_roofline": {"algorithmic_GB_per_step": bytes_step_all / 1e9,
                               "achieved_GBps": bytes_step_all / (dt / args.steps) / 1e9 / world,

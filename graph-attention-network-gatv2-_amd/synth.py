@@ -147,7 +147,8 @@ def make_dataset(name: str, scale: float = 1.0, seed: int = GRAPH_SEED):
                 n=n, e=e, f=f, c=c, name=name)
 
 
-def make_dataset_device(name: str, device, scale: float = 1.0, seed: int = GRAPH_SEED, stream: int = 0, beta: float = 0.75):
+def make_dataset_device(name: str, device, scale: float = 1.0, seed: int = GRAPH_SEED, stream: int = 0, beta: float = 0.75,
+                        sorted_sources: bool = False):
     """The same dataset generated ON the GPU (csrc/gat_synth.hip): the host builds the N-sized tables, the device
     draws and sorts the E sources and fills features and labels.  -> dict(row_ptr (host int32), d_col_idx, d_x,
     d_labels (torch tensors on `device`: feed their data_ptr() to GatContext.set_*_device), n, e, f, c).  Bit-for-bit
@@ -166,6 +167,8 @@ def make_dataset_device(name: str, device, scale: float = 1.0, seed: int = GRAPH
         return order
 
     rp, cdf, nor = graph_tables(n, e, seed, beta, argsort=device_argsort)
+    if sorted_sources:          # experiment (bench.py --sorted-sources): source popularity decreasing with the node id, i.e. what a
+        nor = np.arange(n, dtype=np.int32)      # library-side popularity ordering of the table rows would make of ANY graph
     d_col = torch.empty(max(e, 1), dtype=torch.int32, device=device)
     d_x = torch.empty((n, f), dtype=torch.float32, device=device)
     d_lab = torch.empty(n, dtype=torch.int32, device=device)
