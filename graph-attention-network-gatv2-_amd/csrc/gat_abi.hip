@@ -140,6 +140,8 @@ struct gat_ctx {
     float* msg = nullptr; int32_t msg_hd = 0;       // [E][msg_hd] per-edge message rows (store path)
     uint32_t* stash = nullptr; int32_t stash_words = 0;   // [E][stash_words] per-edge records (stash path: Layer::stash)
     int32_t* csc_dst = nullptr;                     // [E] destination row of every slot (stash path)
+    int32_t* csc_src = nullptr;                     // [E + pad] table row of every slot (slot-parallel source-major pass)
+    gat::SlotRuns runs;                             // its device-side index (csrc null = not built)
     float* gfull = nullptr;                         // [n_rows][HDmax] dL/dh_pre incl. LReLU' (stash path: gathered by the pull pass)
     uint8_t* hbits = nullptr;                       // [n_rows][HD_last/N] LReLU'(h_pre) decisions of the last layer (EdgeBwdArgs::hbits)
     int32_t dbg = 0;                                // GAT_DBG timing experiments (0 = product behaviour)
@@ -303,7 +305,7 @@ static int ensure_buffers(gat_ctx* c) {
         float* m = nullptr;
         // E + 1 rows / records: the last one takes the stores of the group-per-row kernels' padded lanes; kPullPad records of
         // padding behind the records and the destination list: the pull pass reads whole 16-slot chunks without clamping
-        if (hipMalloc((void**)&m, std::max<size_t>((size_t)(E + 1) * msg_hd * (size_t)st_bytes(c), (size_t)(E + kPullPad) * stash_words * sizeof(uint32_t))) == hipSuccess) {
+        if (hipMalloc((void**)&m, std::max<size_t>((size_t)(E + kPullPad) * msg_hd * (size_t)st_bytes(c), (size_t)(E + kPullPad) * stash_words * sizeof(uint32_t))) == hipSuccess) {
             c->owned.push_back(m);
             if (msg_hd > 0) { c->msg = m; c->msg_hd = msg_hd; }
             if (stash_words > 0) {                  // records and message rows are never live at the same time: one buffer
@@ -317,10 +319,27 @@ static int ensure_buffers(gat_ctx* c) {
             }
             GAT_TRY(dalloc(c, &c->csc_pos, E));
             GAT_TRY(dalloc(c, &c->csc_ptr, T + 1));
-            GAT_TRY(build_csc(c->col_idx, E, T, c->csc_pos, c->csc_ptr, c->stream));
+            // slot-parallel source-major pass (gat_csc.hip "runs"): the source of every slot + the lists crossing a run boundary.
+            // GAT_PULL_RUN=<slots per run> (a multiple of 32; 0 = do not build)
+            static const int run_env = [] { const char* e = getenv("GAT_PULL_RUN"); return e ? atoi(e) : -1; }();
+            const int32_t run = run_env >= 0 ? (run_env / 32) * 32 : 64;
+            if (run > 0) GAT_TRY(dalloc(c, &c->csc_src, E + kPullPad));
+            GAT_TRY(build_csc(c->col_idx, E, T, c->csc_pos, c->csc_ptr, c->csc_src, c->stream));
             if (c->csc_dst) GAT_TRY(build_csc_dst(c->row_ptr, c->csc_pos, c->csc_dst, N, E, c->stream));
             HeavyList hl;
-            GAT_TRY(build_heavy_list(c->csc_ptr, T, E, &hl, c->stream));
+            GAT_TRY(build_heavy_list(c->csc_ptr, T, E, &hl, c->stream, run));
+            if (hl.run > 0 && c->csc_src != nullptr) {
+                SlotRuns& R = c->runs;
+                R.run = hl.run; R.n_runs = hl.n_runs; R.n_open = (int32_t)(hl.open.size() / 4); R.n_empty = (int64_t)hl.empty.size();
+                int4* d_open = nullptr; int32_t* d_empty = nullptr;
+                GAT_TRY(dalloc(c, &d_open, std::max<int64_t>(R.n_open, 1)));
+                GAT_TRY(dalloc(c, &d_empty, std::max<int64_t>(R.n_empty, 1)));
+                GAT_TRY(dalloc(c, &R.part, std::max<int64_t>(2 * R.n_runs, 1) * c->HDmax));
+                if (R.n_open > 0) GAT_HIP(hipMemcpyAsync(d_open, hl.open.data(), hl.open.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                if (R.n_empty > 0) GAT_HIP(hipMemcpyAsync(d_empty, hl.empty.data(), hl.empty.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                GAT_HIP(hipStreamSynchronize(c->stream));
+                R.open = d_open; R.empty = d_empty; R.csrc = c->csc_src;
+            }
             c->n_gpl_chunks = (int32_t)(hl.chunks.size() / 4); c->n_gpl_heavy = (int32_t)(hl.heavy.size() / 4);
             if (c->stash != nullptr && !hl.items.empty()) {
                 c->n_pull_items = (int64_t)(hl.items.size() / 4);
@@ -799,7 +818,10 @@ static int plan_backward_edges(gat_ctx* c, int32_t l, BwdPlan* P) {
     // Worth it only when the g rows the pull pass would gather do not stay in the caches (Products shape 627 MB: 2.73 -> 2.29 ms;
     // Arxiv shape 43 MB: the extra loads per slot cost more than the smaller rows save, 1.31 -> 1.25 ms per step without)
     static const int pull_last = [] { const char* e = getenv("GAT_PULL_LAST"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    const bool big_rows = (int64_t)c->n_rows * y.H * y.D * 4 > ((int64_t)128 << 20);
+    // With the slot-parallel pull pass (short lists: shards) the records pay from 64 MB of g rows on: one cache line per slot instead
+    // of two, and that pass is bound by lines per second (Products P = 8 shard, 78 MB: 0.84 -> 0.78 ms per step; Arxiv 43 MB: equal)
+    const bool runs_form = c->runs.csrc != nullptr && c->n_edges < 8 * c->n_table && c->n_edges >= ((int64_t)512 << 10);
+    const bool big_rows = (int64_t)c->n_rows * y.H * y.D * 4 > ((int64_t)(runs_form ? 64 : 128) << 20);
     const bool last_g = stash && a.gh != nullptr && c->hbits != nullptr && !bf16(c) && (pull_last >= 0 ? pull_last == 1 : big_rows) &&
                         c->n_rows < ((int64_t)1 << 26);             // the pull pass addresses the 64-byte node records with 32-bit offsets
     a.hbits = last_g ? c->hbits : nullptr;
@@ -821,12 +843,12 @@ static int sum_backward_edges(gat_ctx* c, int32_t l, const BwdPlan& P) {
         return launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, bf16(c), P.last_g ? c->gH : nullptr, P.last_g ? c->hbits : nullptr, c->gh_stride, 64,
                                a_of(c, l), c->cfg.negative_slope, c->gPL, c->n_table,
                                c->n_edges, y.H, y.D, c->gpl_chunks, c->n_gpl_chunks, c->gpl_heavy, c->n_gpl_heavy, c->gpl_part,
-                               c->pull_items, c->n_pull_items, c->stream);
+                               c->pull_items, c->n_pull_items, c->runs.csrc ? &c->runs : nullptr, c->stream);
     }
     if (P.store) {
         Scope t(c, GAT_K_GPL_SUM);
         return launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, bf16(c), c->gpl_chunks, c->n_gpl_chunks,
-                              c->gpl_heavy, c->n_gpl_heavy, c->gpl_part, c->stream);
+                              c->gpl_heavy, c->n_gpl_heavy, c->gpl_part, c->stream, c->runs.csrc ? &c->runs : nullptr);
     }
     return 0;
 }

@@ -13,6 +13,7 @@
 #include "gat_internal.h"
 
 #include <hipcub/hipcub.hpp>
+#include <utility>
 
 namespace gat {
 namespace {
@@ -128,7 +129,15 @@ __global__ __launch_bounds__(256) void gpl_heavy_fix_kernel(const int4* __restri
     if (k >= n_heavy) return;
     const int4 h = heavy[k];
     float s = 0.f;
-    for (int p = h.y; p < h.y + h.z; ++p) s += part[(int64_t)p * HD + c];
+    int p = h.y;
+    for (; p + 8 <= h.y + h.z; p += 8) {            // eight loads in flight, added in chunk order
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = part[(int64_t)(p + i) * HD + c];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; p < h.y + h.z; ++p) s += part[(int64_t)p * HD + c];
     gPL[(int64_t)h.x * HD + c] = s;
 }
 
@@ -694,6 +703,265 @@ __global__ __launch_bounds__(256) void gpl_pull3_kernel(const int4* __restrict__
     stream_store(reinterpret_cast<V*>(dst + cp * N), acc);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Slot-parallel form of the source-major pass ("runs").  Every kernel above hands a source LIST to a wave or a lane
+// group: per list one descriptor load, then the destination indices, then the gathers — three dependent memory
+// latencies per list, and a pass over a destination-range shard (deg/P slots per source: ~4 at P = 8) is as long
+// as (number of lists) x (latency) / (waves in flight), whatever it moves.  Here the FLAT slot stream is cut into runs of
+// `run` consecutive slots, one run per lane group (64/(HD/N) runs side by side per wave), whatever sources they belong
+// to:
+//   * no per-list descriptor: the group streams csc_src[slot] (4 B per slot) beside the records and destinations;
+//     a slot whose successor has another source ends a segment;
+//   * a segment that lies inside its run is stored straight to gPL[source]; a run's first segment when it began in
+//     an earlier run goes to partial row 2r, its last segment when it continues goes to partial row 2r + 1 (a run
+//     inside one long list: one partial, 2r + 1); gpl_runs_fix_kernel adds the partial rows of every list that
+//     crosses a run boundary in ascending run order.  Fixed cut points, fixed order: bitwise reproducible;
+//   * table rows without slots are zeroed by extra blocks at the front of the same grid (list built once per graph);
+//   * balance is perfect at any degree distribution: no heavy-list chunks, no length-sorted item list.
+// Per slot the messages are rebuilt exactly as in pull_range2 (E:859-869).  Index words reach their lanes by DPP
+// row broadcasts (16-lane groups) instead of LDS shuffles.
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+template <int U, int LPE>
+__device__ __forceinline__ int group_bcast(int v, int gidx) {       // lane U of the caller's group
+    if constexpr (LPE == 16) return __builtin_amdgcn_update_dpp(0, v, 0x150 + U, 0xF, 0xF, false);        // row_newbcast:U
+    else if constexpr (LPE == 4) return __builtin_amdgcn_update_dpp(0, v, U * 0x55, 0xF, 0xF, false);     // quad_perm:[U,U,U,U]
+    else return __shfl(v, gidx * LPE + U);
+}
+
+// below this many slots the runs cannot fill the chip (Pubmed shape: 44 k slots = 173 waves; 0.244 -> 0.268 ms per step with
+// runs, Cora shape 0.190 -> 0.216) and the list-per-wave kernels stay; Arxiv shape (1.17 M slots): 0.256 -> 0.195 ms per step
+constexpr int64_t kRunsMinSlots = 512 << 10;
+struct RunsDev {
+    const int32_t* csrc;       // [n_slots + kPullPad] table row of every slot; -1 behind the last
+    const int32_t* empty;      // [n_empty] table rows without slots
+    float* part;               // [2 n_runs][HD]
+    int64_t n_empty, n_slots, n_table;
+    int32_t run, zero_blocks;
+};
+
+// index words of slot t of the group's run (one lane per slot): d = destination row (gather index; cdst may be null),
+// code = bit 31: a segment ends here | row it is stored to (gPL row, or n_table + partial row)
+__device__ __forceinline__ void runs_index(const RunsDev& rd, const int32_t* __restrict__ cdst, int64_t jb, int64_t r, int cnt, int sb, int dfirst,
+                                           int t, int& d, int& code) {
+    const bool valid = t < cnt;
+    const int64_t j = jb + (valid ? t : 0);
+    const int dv = cdst ? cdst[j] : 0, s0 = rd.csrc[j], s1 = rd.csrc[j + 1];
+    const bool last = t == cnt - 1;
+    const bool endf = valid && (s0 != s1 || last);
+    const int prow = (int)rd.n_table + 2 * (int)r;
+    const int dest = (last && s0 == s1) ? prow + 1 : (s0 == sb ? prow : s0);
+    d = valid ? dv : dfirst;
+    code = endf ? (int)(0x80000000u | (uint32_t)dest) : 0;
+}
+
+template <int HD, int N, bool BF, int LASTD, int U>
+__global__ __launch_bounds__(256) void gpl_pull_runs_kernel(const uint32_t* __restrict__ stash, const int32_t* __restrict__ cdst,
+                                                            const float* __restrict__ gfull, const uint8_t* __restrict__ hbits,
+                                                            const float* __restrict__ a, float slope, float* __restrict__ gPL, RunsDev rd) {
+    using V = typename PullVec<N>::T;
+    constexpr int LPE = HD / N, G = 64 / LPE;
+    constexpr uint32_t kMask = (1u << N) - 1u;
+    static_assert(LPE % U == 0, "batches of U slots");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cp = lane % LPE, gidx = lane / LPE;
+    V acc;
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = 0.f;
+    if ((int)blockIdx.x < rd.zero_blocks) {                 // rows without slots: one row per lane group and step
+        constexpr int kSteps = 8;
+        const int64_t k0 = (int64_t)blockIdx.x * (4 * G * kSteps) + (wave * G + gidx);
+#pragma unroll
+        for (int it = 0; it < kSteps; ++it) {
+            const int64_t k = k0 + (int64_t)it * 4 * G;
+            if (k < rd.n_empty) stream_store(reinterpret_cast<V*>(gPL + (int64_t)rd.empty[k] * HD + cp * N), acc);
+        }
+        return;
+    }
+    const int64_t wv = (int64_t)((int)blockIdx.x - rd.zero_blocks) * 4 + wave;
+    const int64_t r = wv * G + gidx;                        // this group's run
+    const int64_t j0 = r * rd.run, left = rd.n_slots - j0;
+    const int cnt = left <= 0 ? 0 : (left < rd.run ? (int)left : rd.run);
+    const int nT = (__builtin_amdgcn_readfirstlane(cnt) + LPE - 1) / LPE;     // group 0 holds the wave's longest run
+    if (nT == 0) return;
+    const int64_t jb = cnt > 0 ? j0 : 0;                    // a group without slots reads (and ignores) slot 0
+    const int sb = (cnt > 0 && j0 > 0) ? rd.csrc[j0 - 1] : -1;               // source of the slot before the run
+    const int dfirst = cdst[jb];
+    const V ac = *reinterpret_cast<const V*>(a + cp * N);
+    [[maybe_unused]] const V acs = ac * slope;
+    [[maybe_unused]] V mhi, mlo;                              // last layer: 1 / heads and slope / heads
+    if constexpr (LASTD > 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) { mhi[k] = 1.0f / (float)(HD / LASTD); mlo[k] = slope * (1.0f / (float)(HD / LASTD)); }
+    }
+    const char* sp = reinterpret_cast<const char*>(stash + ((uint64_t)jb * LPE + cp));
+    int d, code;
+    runs_index(rd, cdst, jb, r, cnt, sb, dfirst, cp, d, code);
+    for (int T = 0; T < nT; ++T, sp += LPE * LPE * 4) {
+        int dn = 0, coden = 0;
+        if (T + 1 < nT) runs_index(rd, cdst, jb, r, cnt, sb, dfirst, (T + 1) * LPE + cp, dn, coden);
+        if (T * LPE < cnt) {                                // only the launch's last wave has groups that skip
+            const int rem = cnt - T * LPE;
+            static_for(std::make_integer_sequence<int, LPE / U>{}, [&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                uint32_t w[U];
+                V g[U];
+                static_for(std::make_integer_sequence<int, U>{}, [&](auto uc) {
+                    constexpr int u = decltype(uc)::value, slot = b * U + u;
+                    const uint32_t ww = *reinterpret_cast<const uint32_t*>(sp + slot * LPE * 4);     // unclamped: kPullPad
+                    w[u] = slot < rem ? ww : 0u;
+                    const uint32_t drow = (uint32_t)group_bcast<slot, LPE>(d, gidx);
+                    if constexpr (LASTD > 0) {               // 64-byte node records {gH[8] | - | decision bytes at +32}
+                        const uint32_t ro = drow << 6;
+                        const V gh4 = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + (ro + (uint32_t)((cp * N) % LASTD) * 4u));
+                        const uint32_t nib = *reinterpret_cast<const uint8_t*>(reinterpret_cast<const char*>(hbits) + (ro + (uint32_t)cp));
+                        g[u] = gh4 * select_bits<N>(nib, mhi, mlo);
+                    } else if constexpr (BF) {
+                        const char* p = reinterpret_cast<const char*>(gfull) + (drow * (uint32_t)(HD * 2) + (uint32_t)cp * (uint32_t)(N * 2));
+                        if constexpr (N == 2) {
+                            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(p);
+                            g[u][0] = __builtin_bit_cast(float, w2 << 16); g[u][1] = __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+                        } else {
+                            const uint2 w2 = *reinterpret_cast<const uint2*>(p);
+                            g[u][0] = __builtin_bit_cast(float, w2.x << 16); g[u][1] = __builtin_bit_cast(float, w2.x & 0xFFFF0000u);
+                            g[u][2] = __builtin_bit_cast(float, w2.y << 16); g[u][3] = __builtin_bit_cast(float, w2.y & 0xFFFF0000u);
+                        }
+                    } else {
+                        g[u] = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(gfull) + (drow * (uint32_t)(HD * 4) + (uint32_t)cp * (uint32_t)(N * 4)));
+                    }
+                });
+                static_for(std::make_integer_sequence<int, U>{}, [&](auto uc) {
+                    constexpr int u = decltype(uc)::value, slot = b * U + u;
+                    const float val = __builtin_bit_cast(float, w[u] & ~kMask);
+                    const float oth = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, val), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+                    const float al = (cp & 1) ? oth : val, ge = (cp & 1) ? val : oth;
+                    acc += g[u] * al;
+                    acc += select_bits<N>(w[u], ac, acs) * ge;
+                    const int cw = group_bcast<slot, LPE>(code, gidx);
+                    if (cw < 0) {                           // the segment ends with this slot
+                        const uint32_t row = (uint32_t)cw & 0x7fffffffu;
+                        float* dstp = row >= (uint32_t)rd.n_table ? rd.part + (size_t)(row - (uint32_t)rd.n_table) * HD : gPL + (size_t)row * HD;
+                        stream_store(reinterpret_cast<V*>(dstp + cp * N), acc);
+#pragma unroll
+                        for (int i = 0; i < N; ++i) acc[i] = 0.f;
+                    }
+                });
+            });
+        }
+        d = dn; code = coden;
+    }
+}
+
+// The same slot-parallel walk for MESSAGE rows (layers without a record path, bf16 storage at H*D < 64: BASELINE config 5): no
+// gather, the group just streams its run's rows and sums per segment.  A row is LPR lanes x 16 bytes (4 fp32 / 8 bf16 channels
+// per lane); a lane holds the index words of K slots per step so that even a 4-lane group has K*LPR loads in flight.
+template <int HD, bool BF>
+__global__ __launch_bounds__(256) void gpl_sum_runs_kernel(const float* __restrict__ msg, float* __restrict__ gPL, RunsDev rd) {
+    constexpr int CPL = BF ? 8 : 4, LPR = HD / CPL, G = 64 / LPR;
+    constexpr int SS = LPR >= 8 ? LPR : (LPR == 4 ? 16 : 8), K = SS / LPR, U = SS < 8 ? SS : 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane % LPR, gidx = lane / LPR;
+    float acc[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
+    auto store_row = [&](float* rowp) {
+        float4* o = reinterpret_cast<float4*>(rowp + q * CPL);
+        stream_store(o, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        if constexpr (BF) stream_store(o + 1, make_float4(acc[4], acc[5], acc[6], acc[7]));
+    };
+    if ((int)blockIdx.x < rd.zero_blocks) {
+        constexpr int kSteps = 8;
+        const int64_t k0 = (int64_t)blockIdx.x * (4 * G * kSteps) + (wave * G + gidx);
+#pragma unroll
+        for (int it = 0; it < kSteps; ++it) {
+            const int64_t k = k0 + (int64_t)it * 4 * G;
+            if (k < rd.n_empty) store_row(gPL + (int64_t)rd.empty[k] * HD);
+        }
+        return;
+    }
+    const int64_t wv = (int64_t)((int)blockIdx.x - rd.zero_blocks) * 4 + wave;
+    const int64_t r = wv * G + gidx;
+    const int64_t j0 = r * rd.run, left = rd.n_slots - j0;
+    const int cnt = left <= 0 ? 0 : (left < rd.run ? (int)left : rd.run);
+    const int nT = (__builtin_amdgcn_readfirstlane(cnt) + SS - 1) / SS;
+    if (nT == 0) return;
+    const int64_t jb = cnt > 0 ? j0 : 0;
+    const int sb = (cnt > 0 && j0 > 0) ? rd.csrc[j0 - 1] : -1;
+    const char* mp = reinterpret_cast<const char*>(msg) + ((uint64_t)jb * LPR + q) * 16u;
+    int code[K], coden[K], dummy;
+#pragma unroll
+    for (int k = 0; k < K; ++k) runs_index(rd, nullptr, jb, r, cnt, sb, 0, k * LPR + q, dummy, code[k]);
+    for (int T = 0; T < nT; ++T, mp += SS * LPR * 16) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) coden[k] = 0;
+        if (T + 1 < nT) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) runs_index(rd, nullptr, jb, r, cnt, sb, 0, (T + 1) * SS + k * LPR + q, dummy, coden[k]);
+        }
+        if (T * SS < cnt) {
+            const int rem = cnt - T * SS;
+            static_for(std::make_integer_sequence<int, SS / U>{}, [&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                uint4 v[U];
+                static_for(std::make_integer_sequence<int, U>{}, [&](auto uc) {
+                    constexpr int u = decltype(uc)::value, slot = b * U + u;
+                    const uint4 vv = *reinterpret_cast<const uint4*>(mp + slot * LPR * 16);      // unclamped: kPullPad rows behind the last
+                    v[u] = slot < rem ? vv : make_uint4(0u, 0u, 0u, 0u);
+                });
+                static_for(std::make_integer_sequence<int, U>{}, [&](auto uc) {
+                    constexpr int u = decltype(uc)::value, slot = b * U + u;
+                    const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    if constexpr (BF) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            acc[2 * k] += __builtin_bit_cast(float, w[k] << 16);
+                            acc[2 * k + 1] += __builtin_bit_cast(float, w[k] & 0xFFFF0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k] += __builtin_bit_cast(float, w[k]);
+                    }
+                    const int cw = group_bcast<slot % LPR, LPR>(code[slot / LPR], gidx);
+                    if (cw < 0) {
+                        const uint32_t row = (uint32_t)cw & 0x7fffffffu;
+                        store_row(row >= (uint32_t)rd.n_table ? rd.part + (size_t)(row - (uint32_t)rd.n_table) * HD : gPL + (size_t)row * HD);
+#pragma unroll
+                        for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
+                    }
+                });
+            });
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) code[k] = coden[k];
+    }
+}
+
+// open: {source, first run, last run, -}: partial rows 2*r0 + 1, 2*r + 1 for r0 < r < r1, 2*r1, added in that order
+__global__ __launch_bounds__(256) void gpl_runs_fix_kernel(const int4* __restrict__ open, int32_t n_open, const float* __restrict__ part,
+                                                           float* __restrict__ gPL, int32_t Q /* HD / 4 */) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t k = t / Q;
+    const int q = (int)(t % Q);
+    if (k >= n_open) return;
+    const int4 o = open[k];
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    float4 acc = p4[(int64_t)(2 * o.y + 1) * Q + q];
+    int r = o.y + 1;
+    for (; r + 4 <= o.z; r += 4) {                           // loads of four runs in flight, added in run order
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = p4[(int64_t)(2 * (r + i) + 1) * Q + q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc.x += v[i].x; acc.y += v[i].y; acc.z += v[i].z; acc.w += v[i].w; }
+    }
+    for (; r < o.z; ++r) { const float4 v = p4[(int64_t)(2 * r + 1) * Q + q]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    { const float4 v = p4[(int64_t)(2 * o.z) * Q + q]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    reinterpret_cast<float4*>(gPL)[(int64_t)o.x * Q + q] = acc;
+}
+
 // cdst[pos[e]] = row of CSR edge e (binary search in row_ptr, as csr_to_coo_kernel)
 __global__ __launch_bounds__(256) void csc_dst_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ pos,
                                                      int32_t* __restrict__ cdst, int64_t n_rows, int64_t n_edges) {
@@ -721,10 +989,38 @@ int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int
 template <int HD, int N, bool BF, int LASTD>
 static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const uint8_t* hbits,
                     int gh_stride, int hb_stride, const float* a, float slope, float* gPL, int64_t n_table, const int4* chunks, int32_t n_chunks, const int4* heavy,
-                    int32_t n_heavy, float* part, int wpb, int64_t n_slots, const int4* items, int64_t n_items, hipStream_t s) {
+                    int32_t n_heavy, float* part, int wpb, int64_t n_slots, const int4* items, int64_t n_items, const SlotRuns* runs, hipStream_t s) {
+    // Slot-parallel form (gpl_pull_runs_kernel): default where the lists are short (a destination-range shard: the list-per-group
+    // kernel below pays three dependent latencies per ~4 slots); GAT_PULL_RUNS=0|1 forces.  The last layer's variant reads the
+    // 64-byte node records (gh_stride 16, decision bytes at +32).
+    static const int runs_env = [] { const char* e = getenv("GAT_PULL_RUNS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    static const int groups_env = [] { const char* e = getenv("GAT_PULL_GROUPS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool runs_ok = runs != nullptr && runs->csrc != nullptr && runs->run % (HD / N) == 0 && (LASTD == 0 || (gh_stride == 16 && hb_stride == 64));
+    if (runs_ok && (runs_env >= 0 ? runs_env == 1 : (groups_env < 0 && n_slots < 8 * n_table && n_slots >= kRunsMinSlots))) {     // an explicit GAT_PULL_GROUPS selects among the list kernels
+        constexpr int G = 64 / (HD / N), U = (HD / N) % 8 == 0 ? 8 : 4;
+        RunsDev rd{};
+        rd.csrc = runs->csrc; rd.empty = runs->empty; rd.part = runs->part; rd.n_empty = runs->n_empty; rd.n_slots = n_slots; rd.n_table = n_table;
+        rd.run = runs->run; rd.zero_blocks = (int32_t)((runs->n_empty + 4 * G * 8 - 1) / (4 * G * 8));
+        const int64_t waves = (runs->n_runs + G - 1) / G, blocks = rd.zero_blocks + (waves + 3) / 4;
+        static const int u_env = [] { const char* e = getenv("GAT_PULL_U"); return e ? atoi(e) : 0; }();      // experiment: slots per batch (16-lane groups)
+        if (blocks > 0) {
+            if constexpr (HD / N == 16 && !BF) {
+                if (u_env == 4) hipLaunchKernelGGL((gpl_pull_runs_kernel<HD, N, BF, LASTD, 4>), dim3((unsigned)blocks), dim3(256), 0, s, stash, cdst, gfull, hbits, a, slope, gPL, rd);
+                else if (u_env == 16) hipLaunchKernelGGL((gpl_pull_runs_kernel<HD, N, BF, LASTD, 16>), dim3((unsigned)blocks), dim3(256), 0, s, stash, cdst, gfull, hbits, a, slope, gPL, rd);
+                else hipLaunchKernelGGL((gpl_pull_runs_kernel<HD, N, BF, LASTD, U>), dim3((unsigned)blocks), dim3(256), 0, s, stash, cdst, gfull, hbits, a, slope, gPL, rd);
+            } else {
+                hipLaunchKernelGGL((gpl_pull_runs_kernel<HD, N, BF, LASTD, U>), dim3((unsigned)blocks), dim3(256), 0, s, stash, cdst, gfull, hbits, a, slope, gPL, rd);
+            }
+        }
+        if (runs->n_open > 0) {
+            const int64_t threads = (int64_t)runs->n_open * (HD / 4);
+            hipLaunchKernelGGL(gpl_runs_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, runs->open, runs->n_open, runs->part, gPL, HD / 4);
+        }
+        GAT_HIP(hipGetLastError());
+        return 0;
+    }
     // GAT_PULL_GROUPS=1: the group-per-source kernel.  Measured SLOWER on the Products shape (5.8 vs 5.36 ms per step), as was
     // everything else that shortened this pass's dependency chains or shrank its gathers: see DESIGN §4 (random-row rate)
-    static const int groups_env = [] { const char* e = getenv("GAT_PULL_GROUPS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     // default: groups only where the lists are short (a destination-range shard sees ~deg/P slots per source: one wave
     // per 3-slot list wastes 15 of its 16 gather slots) — the same rule the message-row sum used (n_slots < 8 n_table)
     // ... and only with enough lists to give every resident wave several (Pubmed shape, 19,717 lists: one wave per list 0.27 vs 0.30 ms per step)
@@ -779,14 +1075,14 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
 int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16,
                     const float* gh, const uint8_t* hbits, int32_t gh_stride, int32_t hb_stride, const float* a,
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
-                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, hipStream_t s) {
+                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, const SlotRuns* runs, hipStream_t s) {
     if (n_table <= 0) return 0;
     // one wave per block for the pull kernel (GAT_GPL_WAVES=1|2|4): 5.03 / 5.11 / 5.30 ms per step on the Products shape — a
     // 4-wave block lives as long as its longest list; the message-row sum (launch_gpl_sum) measured the other way round
     static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
     const int HD = H * D;
     const bool last = gh != nullptr && hbits != nullptr;
-#define PULL_ARGS(G_) src_ptr, stash, cdst, G_, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, items, n_items, s
+#define PULL_ARGS(G_) src_ptr, stash, cdst, G_, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, items, n_items, runs, s
 #define PULL(HD_, N_, D_)                                                                           \
     {                                                                                               \
         if (last) return run_pull<HD_, N_, false, D_>(PULL_ARGS(gh));                               \
@@ -804,7 +1100,8 @@ int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
 }
 
 int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t* pos, int32_t* src_ptr,
-              hipStream_t s) {
+              int32_t* csrc, hipStream_t s) {
+    if (csrc) GAT_HIP(hipMemsetAsync(csrc + std::max<int64_t>(n_edges, 0), 0xFF, (size_t)kPullPad * sizeof(int32_t), s));      // -1: no source
     if (n_edges <= 0) {
         GAT_HIP(hipMemsetAsync(src_ptr, 0, (size_t)(n_table + 1) * sizeof(int32_t), s));
         return 0;
@@ -828,6 +1125,7 @@ int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t*
     CSC_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, col_idx, keys_out, iota, perm, (int)n_edges, 0,
                                                end_bit, s));
     hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)blocks), dim3(256), 0, s, perm, pos, n_edges);
+    if (csrc) CSC_HIP(hipMemcpyAsync(csrc, keys_out, (size_t)n_edges * sizeof(int32_t), hipMemcpyDeviceToDevice, s));      // the sorted keys = source of every slot
     const int64_t sblocks = std::min<int64_t>((n_table + 1 + 255) / 256, 65536);
     hipLaunchKernelGGL(segment_offsets_kernel, dim3((unsigned)sblocks), dim3(256), 0, s, keys_out, n_edges, src_ptr,
                        n_table);
@@ -838,12 +1136,24 @@ int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t*
     return rc;
 }
 
-int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, int64_t n_edges, HeavyList* out, hipStream_t s) {
+int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, int64_t n_edges, HeavyList* out, hipStream_t s, int32_t run) {
     out->chunks.clear(); out->heavy.clear();
+    out->run = 0; out->n_runs = 0; out->open.clear(); out->empty.clear();
     if (n_table <= 0) return 0;
     std::vector<int32_t> ptr((size_t)n_table + 1);
     GAT_HIP(hipMemcpyAsync(ptr.data(), d_src_ptr, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     GAT_HIP(hipStreamSynchronize(s));
+    // slot-parallel form: runs of `run` consecutive slots — the lists that cross a run boundary (their partial rows are added by
+    // gpl_runs_fix_kernel) and the table rows without slots (zeroed by the runs kernel's first blocks)
+    if (run > 0 && n_table + 2 * ((n_edges + run - 1) / run) + 2 < 0x7fffffffLL) {
+        out->run = run; out->n_runs = (n_edges + run - 1) / run;
+        for (int64_t src = 0; src < n_table; ++src) {
+            const int32_t b = ptr[(size_t)src], e = ptr[(size_t)src + 1];
+            if (e == b) { out->empty.push_back((int32_t)src); continue; }
+            const int32_t r0 = b / run, r1 = (e - 1) / run;
+            if (r0 != r1) out->open.insert(out->open.end(), {(int32_t)src, r0, r1, 0});
+        }
+    }
     const int kHeavySlots = heavy_slots(n_edges);
     out->threshold = kHeavySlots;
     out->items.clear();
@@ -895,8 +1205,35 @@ static int run_heavy(const float* msg, float* gPL, bool bf, const int4* chunks, 
 
 int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
                    int32_t HD, bool msg_bf16, const int4* chunks, int32_t n_chunks, const int4* heavy,
-                   int32_t n_heavy, float* part, hipStream_t s) {
+                   int32_t n_heavy, float* part, hipStream_t s, const SlotRuns* runs) {
     if (n_table <= 0) return 0;
+    // slot-parallel form (gpl_sum_runs_kernel): the default on short lists (a destination-range shard) of fp32 rows; GAT_PULL_RUNS=0|1
+    // forces.  Not for bf16 rows: a 64-byte row is FOUR lanes, and a segment end is a store instruction of its own per group (two
+    // half-line requests per 128-byte gPL row), where the list kernel's 16 groups store 16 consecutive rows with one instruction —
+    // BASELINE config 5's P = 8 shard measured 1.49-1.54 ms per step against 1.31 (profiles/r04/experiments)
+    static const int runs_env = [] { const char* e = getenv("GAT_PULL_RUNS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    static const bool group_env = getenv("GAT_GPL_GROUP") != nullptr || getenv("GAT_GPL_BF16_GROUP") != nullptr;
+    if (runs != nullptr && runs->csrc != nullptr && runs->run % 16 == 0 && (HD == 64 || HD == 32 || HD == 16 || HD == 8) &&
+        (runs_env >= 0 ? runs_env == 1 : (!group_env && !msg_bf16 && n_slots < 8 * n_table && n_slots >= kRunsMinSlots))) {
+        const int G = 64 / (HD / (msg_bf16 ? 8 : 4));
+        RunsDev rd{};
+        rd.csrc = runs->csrc; rd.empty = runs->empty; rd.part = runs->part; rd.n_empty = runs->n_empty; rd.n_slots = n_slots; rd.n_table = n_table;
+        rd.run = runs->run; rd.zero_blocks = (int32_t)((runs->n_empty + 4 * G * 8 - 1) / (4 * G * 8));
+        const int64_t waves = (runs->n_runs + G - 1) / G, blocks = rd.zero_blocks + (waves + 3) / 4;
+        const dim3 grid((unsigned)blocks), block(256);
+        if (blocks > 0) {
+#define SUM_RUNS(HD_) do { if (msg_bf16) hipLaunchKernelGGL((gpl_sum_runs_kernel<HD_, true>), grid, block, 0, s, msg, gPL, rd); \
+                           else hipLaunchKernelGGL((gpl_sum_runs_kernel<HD_, false>), grid, block, 0, s, msg, gPL, rd); } while (0)
+            switch (HD) { case 64: SUM_RUNS(64); break; case 32: SUM_RUNS(32); break; case 16: SUM_RUNS(16); break; default: SUM_RUNS(8); break; }
+#undef SUM_RUNS
+        }
+        if (runs->n_open > 0) {
+            const int64_t threads = (int64_t)runs->n_open * (HD / 4);
+            hipLaunchKernelGGL(gpl_runs_fix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, runs->open, runs->n_open, runs->part, gPL, HD / 4);
+        }
+        GAT_HIP(hipGetLastError());
+        return 0;
+    }
     if (n_heavy > 0) {                                  // long lists first: they are the longest-running waves
         switch (HD) {
             case 64: GAT_TRY(run_heavy<64>(msg, gPL, msg_bf16, chunks, n_chunks, heavy, n_heavy, part, s)); break;

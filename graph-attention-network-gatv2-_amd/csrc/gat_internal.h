@@ -144,19 +144,34 @@ int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D, bool store, bool
 bool edge_fast_path(int32_t H, int32_t D, int64_t n_table);
 
 // ---- source-major slot index + segmented sum (gat_csc.hip) ----------------------------------------
+// csrc (optional): [n_edges + kPullPad] table row of every slot (the sorted keys), -1 in the padding
 int build_csc(const int32_t* col_idx, int64_t n_edges, int64_t n_table, int32_t* pos, int32_t* src_ptr,
-              hipStream_t s);
+              int32_t* csrc, hipStream_t s);
 // sources with long slot lists, cut into chunks (gat_csc.hip kHeavySlots): built once per graph from the CSC pointers
 struct HeavyList {
     std::vector<int32_t> chunks;    // int4 {first slot, end slot, partial row, -}
     std::vector<int32_t> heavy;     // int4 {source, first partial, partial count, -}
     int32_t threshold = 0;          // slots above which a list is chunked (depends on the graph size)
     std::vector<int32_t> items;     // int4 {source, first slot, end slot, partial row | -1}: chunks first, then the other sources by length
+    // slot-parallel form (SlotRuns): run length (0 = not built), number of runs, lists crossing a run boundary, rows without slots
+    int32_t run = 0; int64_t n_runs = 0;
+    std::vector<int32_t> open;      // int4 {source, first run, last run, -}
+    std::vector<int32_t> empty;     // table rows without slots
 };
-int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, int64_t n_edges, HeavyList* out, hipStream_t s);
+int build_heavy_list(const int32_t* d_src_ptr, int64_t n_table, int64_t n_edges, HeavyList* out, hipStream_t s, int32_t run = 0);
+// Slot-parallel ("runs") form of the source-major pass (gat_csc.hip gpl_pull_runs_kernel): the flat slot stream cut into runs of
+// `run` slots, one per lane group, segmented by a streamed source id per slot.  Device-side index, built once per graph.
+struct SlotRuns {
+    const int32_t* csrc = nullptr;      // [n_slots + kPullPad] table row of every slot, -1 behind the last
+    int32_t run = 0;                    // slots per run (a multiple of 32)
+    int64_t n_runs = 0;
+    const int4* open = nullptr; int32_t n_open = 0;       // lists crossing a run boundary {source, first run, last run, -}
+    const int32_t* empty = nullptr; int64_t n_empty = 0;  // table rows without slots
+    float* part = nullptr;              // [2 n_runs][HDmax] partial rows of the runs' open segments
+};
 int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t n_table, int64_t n_slots,
                    int32_t HD, bool msg_bf16, const int4* chunks, int32_t n_chunks, const int4* heavy,
-                   int32_t n_heavy, float* part, hipStream_t s);
+                   int32_t n_heavy, float* part, hipStream_t s, const SlotRuns* runs = nullptr);
 // slots of padding behind the record buffer and the destination list: the pull pass reads whole 16-slot chunks (and one chunk
 // of destinations ahead) without clamping its indices
 constexpr int64_t kPullPad = 32;
@@ -167,7 +182,7 @@ int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int
 int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16,
                     const float* gh, const uint8_t* hbits, int32_t gh_stride, int32_t hb_stride, const float* a,
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
-                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, hipStream_t s);
+                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, const SlotRuns* runs, hipStream_t s);
 
 int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);

@@ -23,8 +23,10 @@ SNIPPET = """
     SHAPES = [((8, 8), (8, 8)), ((4, 4), (8, 8)), ((8, 1), (8, 8)), ((2, 4), (4, 8)), ((16, 8), (4, 4)), ((4, 2), (16, 8)),
               ((1, 8), (8, 4)), ((8, 8, 8), (8, 4, 8)), ((3, 2), (8, 8))]
     rng = np.random.default_rng({seed})
-    skipped = 0
-    for case in range({cases}):
+    skipped = ran = draws = 0
+    while ran < {cases} and draws < 4 * {cases}:       # an ill-conditioned draw (below) is REDRAWN: {cases} cases are checked per setting
+        case = draws
+        draws += 1
         heads, outdims = SHAPES[rng.integers(len(SHAPES))]
         n = int(rng.choice([1, 2, 3, 5, 17, 64, 130, 257]))
         f = int(rng.choice([3, 8, 20, 33]))
@@ -59,6 +61,7 @@ SNIPPET = """
         if cond > 2e-5:
             skipped += 1
             continue
+        ran += 1
         parity.set_test("fuzz{tag} case %d: heads %s outdims %s n %d e %d" % (case, heads, outdims, n, len(ci)))
         with pkg.GatContext(cfg.heads, cfg.outdims, f, c) as ctx:
             ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
@@ -73,8 +76,9 @@ SNIPPET = """
             scale = float(max(np.abs(ref.gradW).max(), 1e-20))
             parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx, floor=1e-3 * scale)
     parity.flush()
-    assert skipped <= ({cases} + 1) // 2, skipped          # ill-conditioned draws (see above) say nothing about the kernels; most cases must run
-    print("OK skipped", skipped)
+    assert ran == {cases}, (ran, draws, skipped)           # every setting checks the full number of well-conditioned cases
+    assert skipped <= max(draws // 3, 2), (skipped, draws)  # a statement about the DRAW: ill-conditioned graphs must stay the exception
+    print("OK ran", ran, "draws", draws, "skipped", skipped)
 """
 
 
@@ -84,11 +88,15 @@ def _run(env, seed, cases, tag):
     assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
 
-# 6 switch settings x 6 cases (~22 s each on the test box; 5 x 24 cases were run once when the kernels were written, 6 x 9 in round 3)
+# 9 switch settings x 9 checked cases (ill-conditioned draws are redrawn, not forgiven: VERDICT r3 / ADVICE r3)
 @pytest.mark.parametrize("env,tag", [({}, ""), ({"GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"}, " groups, tiny segments"),
                                      ({"GAT_PULL_GROUPS": "0", "GAT_PULL_LAST": "0"}, " waves"), ({"GAT_ROWGROUP": "0"}, " chunked"),
                                      ({"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"}, " last-layer records, groups"),
                                      ({"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "0", "GAT_ROWGROUP": "0"}, " last-layer records, waves, chunked"),
-                                     ({"GAT_FUSE_LAST": "1", "GAT_PULL_LAST": "1"}, " last layer fused per row")])
+                                     ({"GAT_FUSE_LAST": "1", "GAT_PULL_LAST": "1"}, " last layer fused per row"),
+                                     # slot-parallel source-major pass (gat_csc.hip "runs") forced, gfull and node-record variants, short runs
+                                     ({"GAT_PULL_RUNS": "1", "GAT_PULL_RUN": "32", "GAT_PULL_LAST": "0"}, " slot runs of 32"),
+                                     ({"GAT_PULL_RUNS": "1", "GAT_PULL_LAST": "1", "GAT_SEG_EDGES": "16"}, " slot runs, last-layer records"),
+                                     ({"GAT_PULL_RUNS": "1", "GAT_BWD_STASH": "0"}, " slot runs, message rows")])
 def test_random_small_cases(env, tag):
-    _run(env, 20260 + len(tag), 6, tag)
+    _run(env, 20260 + len(tag), 9, tag)

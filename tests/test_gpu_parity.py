@@ -380,7 +380,11 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
                                  {"GAT_PULL_V2": "2", "GAT_PULL_LAST": "0", "GAT_GPL_HEAVY": "16"},
                                  # the last layer fused per row (edge_last_fused_kernel: measured, off by default — DESIGN §4 "Round 3"), with the
                                  # gfull and the node-record variants of what it leaves for the pull pass, many split rows (16-edge segments)
-                                 {"GAT_FUSE_LAST": "1"}, {"GAT_FUSE_LAST": "1", "GAT_PULL_LAST": "1", "GAT_SEG_EDGES": "16"}])
+                                 {"GAT_FUSE_LAST": "1"}, {"GAT_FUSE_LAST": "1", "GAT_PULL_LAST": "1", "GAT_SEG_EDGES": "16"},
+                                 # slot-parallel source-major pass ("runs": the default on short lists / shards) forced on this graph's long
+                                 # lists (a 700-slot hub source crosses many runs), both g variants, record and message-row layers
+                                 {"GAT_PULL_RUNS": "1", "GAT_PULL_RUN": "32", "GAT_PULL_LAST": "0"}, {"GAT_PULL_RUNS": "1", "GAT_PULL_LAST": "1"},
+                                 {"GAT_PULL_RUNS": "1", "GAT_BWD_STASH": "0"}, {"GAT_PULL_RUNS": "0", "GAT_PULL_GROUPS": "1"}])
 def test_ab_switches_stay_correct(pkg, orc, env):
     """The A/B switches of DESIGN §7 select other kernels / launch shapes for the SAME math: each must still
     match the oracle (they are read once per process, hence a subprocess)."""
