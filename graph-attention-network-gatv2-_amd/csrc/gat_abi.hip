@@ -129,6 +129,12 @@ struct gat_ctx {
     int32_t HDmax = 0, Hmax = 0;
     float* gPL = nullptr; bool gPL_bound = false;   // [n_table][HDmax]
     float* gPR = nullptr;                           // [n_rows][HDmax]
+    // grad_w off the edge passes' stream (gat_backward / gat_step): a second gPL / gPR pair for the odd layers, so that layer l's
+    // grad_w may still read its operands while layer l-1's edge passes write theirs; side stream + fork / join events per layer
+    float* gPL_alt = nullptr; float* gPR_alt = nullptr;
+    bool ov_active = false;                         // inside backward_phases with the overlap on: odd layers use the second pair
+    hipStream_t side_stream = nullptr;
+    std::vector<hipEvent_t> ev_fork, ev_join;
     float* gH = nullptr;                            // [n_rows][gh_stride] head-independent output gradient (HeadBwdArgs::gh_out)
     int32_t gh_stride = 0;                          // D_last, or 16: 64-B records {gH row | the row's LReLU'(h_pre) decision bytes at +32}
     bool y_valid = false;                           // c->y holds the last forward's probabilities (not after a fused head step)
@@ -198,19 +204,19 @@ static int flush_events(gat_ctx* c) {
     c->ev_pending.clear();
     return 0;
 }
-struct Scope {      // brackets the launches of one kernel class with a HIP event pair
-    gat_ctx* c; int k; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
-    Scope(gat_ctx* c_, int k_) : c(c_), k(k_), on(c_->cfg.collect_timing != 0) {
+struct Scope {      // brackets the launches of one kernel class with a HIP event pair (on the stream they are launched on)
+    gat_ctx* c; int k; hipEvent_t e0 = nullptr, e1 = nullptr; bool on; hipStream_t st;
+    Scope(gat_ctx* c_, int k_, hipStream_t st_ = nullptr) : c(c_), k(k_), on(c_->cfg.collect_timing != 0), st(st_ ? st_ : c_->stream) {
         if (!on) return;
         if (c->ev_pending.size() >= 2048) (void)flush_events(c);
         if (c->ev_free.empty()) {
             if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
         } else { e0 = c->ev_free.back().first; e1 = c->ev_free.back().second; c->ev_free.pop_back(); }
-        (void)hipEventRecord(e0, c->stream);
+        (void)hipEventRecord(e0, st);
     }
     ~Scope() {
         if (!on) return;
-        (void)hipEventRecord(e1, c->stream);
+        (void)hipEventRecord(e1, st);
         c->ev_pending.push_back({k, e0, e1});
     }
 };
@@ -232,6 +238,8 @@ static float* gW_of(gat_ctx* c, int l) { return c->grads + c->layers[l].w_off; }
 static float* ga_of(gat_ctx* c, int l) { return c->grads + c->nW + c->layers[l].a_off; }
 static float* gWo_of(gat_ctx* c) { return c->grads + c->nW + c->nA; }
 static const float* Xin_of(gat_ctx* c, int l) { return l == 0 ? c->X0 : c->layers[l - 1].hout; }
+static float* gPL_of(gat_ctx* c, int l) { return (c->ov_active && (l & 1)) ? c->gPL_alt : c->gPL; }
+static float* gPR_of(gat_ctx* c, int l) { return (c->ov_active && (l & 1)) ? c->gPR_alt : c->gPR; }
 
 // (re)allocate everything that depends on the graph size
 static int ensure_buffers(gat_ctx* c) {
@@ -471,6 +479,9 @@ int gat_destroy(gat_ctx* c) {
     c->comm.reset();
     for (hipEvent_t e : c->comm_events) (void)hipEventDestroy(e);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    for (hipEvent_t e : c->ev_fork) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_join) (void)hipEventDestroy(e);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     if (c->pinned_tail) (void)hipHostFree(c->pinned_tail);
@@ -809,7 +820,7 @@ static int plan_backward_edges(gat_ctx* c, int32_t l, BwdPlan* P) {
     EdgeBwdArgs a{};
     a.row_ptr = c->row_ptr; a.col_idx = c->col_idx; a.PL = y.PL; a.PR = y.PR; a.a = a_of(c, l);
     a.alpha = y.alpha; a.mstat = y.mstat; a.zstat = y.zstat;
-    a.hpre = y.hpre; a.g = y.g; a.gPL = c->gPL; a.gPR = c->gPR; a.ge = y.ge; a.galpha = y.galpha;
+    a.hpre = y.hpre; a.g = y.g; a.gPL = gPL_of(c, l); a.gPR = gPR_of(c, l); a.ge = y.ge; a.galpha = y.galpha;
     a.g_raw = l < c->cfg.num_layers - 1;           // hidden layers: written by launch_grad_x without the LReLU' factor
     a.gh = (l == c->cfg.num_layers - 1) ? c->gH : nullptr; a.gh_stride = c->gh_stride; a.hb_stride = 64;
     a.pos = store ? c->csc_pos : nullptr; a.msg = store ? c->msg : nullptr;
@@ -841,13 +852,13 @@ static int sum_backward_edges(gat_ctx* c, int32_t l, const BwdPlan& P) {
     if (P.stash) {
         Scope t(c, GAT_K_GPL_SUM);
         return launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, bf16(c), P.last_g ? c->gH : nullptr, P.last_g ? c->hbits : nullptr, c->gh_stride, 64,
-                               a_of(c, l), c->cfg.negative_slope, c->gPL, c->n_table,
+                               a_of(c, l), c->cfg.negative_slope, gPL_of(c, l), c->n_table,
                                c->n_edges, y.H, y.D, c->gpl_chunks, c->n_gpl_chunks, c->gpl_heavy, c->n_gpl_heavy, c->gpl_part,
                                c->pull_items, c->n_pull_items, c->runs.csrc ? &c->runs : nullptr, c->stream);
     }
     if (P.store) {
         Scope t(c, GAT_K_GPL_SUM);
-        return launch_gpl_sum(c->csc_ptr, c->msg, c->gPL, c->n_table, c->n_edges, y.HD, bf16(c), c->gpl_chunks, c->n_gpl_chunks,
+        return launch_gpl_sum(c->csc_ptr, c->msg, gPL_of(c, l), c->n_table, c->n_edges, y.HD, bf16(c), c->gpl_chunks, c->n_gpl_chunks,
                               c->gpl_heavy, c->n_gpl_heavy, c->gpl_part, c->stream, c->runs.csrc ? &c->runs : nullptr);
     }
     return 0;
@@ -859,7 +870,7 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     GAT_TRY(plan_backward_edges(c, l, &P));
     if (!P.store) {
         Scope t(c, GAT_K_MISC);
-        GAT_HIP(hipMemsetAsync(c->gPL, 0, (size_t)c->n_table * y.HD * sizeof(float), c->stream));
+        GAT_HIP(hipMemsetAsync(gPL_of(c, l), 0, (size_t)c->n_table * y.HD * sizeof(float), c->stream));
     }
     {
         Scope t(c, GAT_K_EDGE_BWD);
@@ -870,25 +881,31 @@ int gat_layer_backward_edges(gat_ctx* c, int32_t l) {
     return launch_reduce_partials_add(P.a.ga_partial, P.a.ga_blocks, y.HD, ga_of(c, l), c->stream);
 }
 
-int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
-    GAT_TRY(check_layer(c, l));
+// grad_w of layer l on stream st (the context's, or the side stream of the overlapped backward)
+static int backward_grad_w(gat_ctx* c, int32_t l, hipStream_t st) {
     Layer& y = c->layers[l];
-    const float* gPL_rows = c->gPL + c->table_row0 * y.HD;
-    {
-        Scope t(c, GAT_K_GRAD_W);
-        if (l == 0 && c->Xtab) {  // partial gPL over the whole table x replicated input; the gradient all-reduce sums shards
-            GAT_TRY(launch_grad_w(c->gPL, nullptr, c->Xtab, gW_of(c, l), c->gw_scratch, c->n_table, y.F, y.HD, kPartLeft, c->stream));
-            GAT_TRY(launch_grad_w(nullptr, c->gPR, c->X0, gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, kPartRight, c->stream));
-        } else {
-            GAT_TRY(launch_grad_w(gPL_rows, c->gPR, Xin_of(c, l), gW_of(c, l), c->gw_scratch + c->gw_off[(size_t)l], c->n_rows, y.F, y.HD, kPartBoth, c->stream));
-        }
+    const float* gPL_rows = gPL_of(c, l) + c->table_row0 * y.HD;
+    Scope t(c, GAT_K_GRAD_W, st);
+    if (l == 0 && c->Xtab) {  // partial gPL over the whole table x replicated input; the gradient all-reduce sums shards
+        GAT_TRY(launch_grad_w(gPL_of(c, l), nullptr, c->Xtab, gW_of(c, l), c->gw_scratch, c->n_table, y.F, y.HD, kPartLeft, st));
+        return launch_grad_w(nullptr, gPR_of(c, l), c->X0, gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, kPartRight, st);
     }
+    return launch_grad_w(gPL_rows, gPR_of(c, l), Xin_of(c, l), gW_of(c, l), c->gw_scratch + c->gw_off[(size_t)l], c->n_rows, y.F, y.HD, kPartBoth, st);
+}
+static int backward_grad_x(gat_ctx* c, int32_t l) {
     if (l == 0) return 0;                                             // E:1528
+    Layer& y = c->layers[l];
+    const float* gPL_rows = gPL_of(c, l) + c->table_row0 * y.HD;
     Scope t(c, GAT_K_GRAD_X);
     // plain dL/d(input) of this layer: the LReLU'(h_pre) factor of E:888-892 is applied by the edge backward
     // of layer l-1, which reads h_pre anyway (the epilogue's extra read of h_pre cost 0.45 of 1.03 ms)
-    return launch_grad_x(gPL_rows, c->gPR, W_of(c, l), nullptr, c->layers[l - 1].g, c->n_rows, y.F, y.HD,
+    return launch_grad_x(gPL_rows, gPR_of(c, l), W_of(c, l), nullptr, c->layers[l - 1].g, c->n_rows, y.F, y.HD,
                          c->cfg.negative_slope, c->stream);
+}
+int gat_layer_backward_dense(gat_ctx* c, int32_t l) {
+    GAT_TRY(check_layer(c, l));
+    GAT_TRY(backward_grad_w(c, l, c->stream));
+    return backward_grad_x(c, l);
 }
 
 // ---- whole step (single shard, or a shard with a transport attached) ------------------------------------------
@@ -1042,18 +1059,83 @@ static int last_layer_fused(gat_ctx* c) {
     Scope t(c, GAT_K_MISC);
     return launch_reduce_partials_add(ga_a, blocks_a + a.b.ga_blocks, y.HD, ga_of(c, l), c->stream);
 }
+// grad_w of a layer feeds nothing but the parameter gradients, yet on one stream it sits between the layer's source-major pass
+// and grad_x -> the next layer's edge passes (E:1517 vs 1533).  With GAT_OVERLAP=1 it runs on a side stream: forked after the
+// layer's gPL is complete, joined before that layer's buffer pair is written again (two layers later) or at the end of the
+// backward.  MEASURED, NOT THE DEFAULT (DESIGN §4 "Round 4", profiles/r04/experiments/overlap_*): Products shape, same box,
+// A/B/A/B 20.98 / 21.18 / 21.21 / 21.42 ms per step and 21.15 / 21.29 / 21.17 / 22.36 with a lowest-priority side stream — the
+// 0.31 ms of layer 1's grad_w leave the critical path, and the backward edge pass it runs beside (a persistent grid sized to
+// the chip, items dealt statically: any CU that shares its wave slots and fabric requests becomes the tail) slows by
+// 0.33-0.36 ms, grad_x by 0.06, grad_w itself from 0.79 to 1.29; under hipGraph replay the fork / join costs more than it hides
+// (Arxiv shape 1.12 -> 1.16 ms, Pubmed 0.245 -> 0.263, Cora 0.188 -> 0.202).  The edge passes are bound by fabric requests
+// per second, which the dense kernels (4-6 TB/s of row streaming) consume too: there is no idle unit to fill.  Needs the second gPL / gPR pair (odd layers), hence not with a caller-bound gPL table
+// or a replicated layer-0 input (its two grad_w launches share one slab region).  Same kernels, same operands: bitwise the
+// serial order's gradients.  Captured by gat_step_graph as a fork / join in the graph.
+static int overlap_prepare(gat_ctx* c) {
+    static const int env = [] { const char* e = getenv("GAT_OVERLAP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const int L = c->cfg.num_layers;
+    const bool want = env == 1;
+    if (!want || L < 2 || c->gPL_bound || c->Xtab) return 0;
+    if (!c->gPL_alt) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(c->stream, &cs);
+        if (cs != hipStreamCaptureStatusNone) return 0;               // first use inside a capture: allocate on the next eager step
+        GAT_TRY(dalloc(c, &c->gPL_alt, c->n_table * c->HDmax));
+        GAT_TRY(dalloc(c, &c->gPR_alt, c->n_rows * c->HDmax));
+        {   // lowest priority: grad_w should fill what the edge passes leave free (their tails), not take their wave slots
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            static const bool prio = [] { const char* e = getenv("GAT_OVERLAP_PRIO"); return !(e && e[0] == '0'); }();
+            if (prio) GAT_HIP(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
+            else GAT_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        }
+        for (int l = 0; l < L; ++l) {
+            hipEvent_t a, b;
+            GAT_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            GAT_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            c->ev_fork.push_back(a); c->ev_join.push_back(b);
+        }
+    }
+    return 1;
+}
+struct OverlapScope {       // ov_active only while backward_phases runs (the phase API keeps the single pair)
+    gat_ctx* c;
+    explicit OverlapScope(gat_ctx* c_, bool on) : c(c_) { c->ov_active = on; }
+    ~OverlapScope() { c->ov_active = false; }
+};
 static int backward_phases(gat_ctx* c, bool head_done = false, bool last_edges_done = false) {
     // last_edges_done: the last layer's edge passes (incl. its source-major pass) have run already (fused last layer)
+    const int L = c->cfg.num_layers;
+    const int ov = last_edges_done ? 0 : overlap_prepare(c);          // (the fused last layer wrote the first pair before this call)
+    if (ov < 0) return ov;
+    OverlapScope scope(c, ov == 1);
+    std::vector<char> forked((size_t)L, 0);
     if (!head_done) GAT_TRY(gat_head_backward(c));
-    for (int l = c->cfg.num_layers - 1; l >= 0; --l) {
-        if (!(last_edges_done && l == c->cfg.num_layers - 1)) GAT_TRY(gat_layer_backward_edges(c, l));
+    for (int l = L - 1; l >= 0; --l) {
+        if (ov && l + 2 < L && forked[(size_t)l + 2]) {               // this layer rewrites the pair layer l+2's grad_w reads
+            GAT_HIP(hipStreamWaitEvent(c->stream, c->ev_join[(size_t)l + 2], 0));
+            forked[(size_t)l + 2] = 0;
+        }
+        if (!(last_edges_done && l == L - 1)) GAT_TRY(gat_layer_backward_edges(c, l));
         if (c->comm && needs_exchange(c, l)) {
             Scope t(c, GAT_K_EXCHANGE);
-            if (c->comm_gpl_bf16) GAT_TRY(c->comm->reduce_scatter_bf16(c->gPL, table_slice(c, c->layers[l]), c->stream));
-            else GAT_TRY(c->comm->reduce_scatter(c->gPL, table_slice(c, c->layers[l]), c->stream));
+            if (c->comm_gpl_bf16) GAT_TRY(c->comm->reduce_scatter_bf16(gPL_of(c, l), table_slice(c, c->layers[l]), c->stream));
+            else GAT_TRY(c->comm->reduce_scatter(gPL_of(c, l), table_slice(c, c->layers[l]), c->stream));
         }
-        GAT_TRY(gat_layer_backward_dense(c, l));
+        if (ov && l > 0) {                                            // layer 0's grad_w is the last kernel: nothing to hide behind
+            GAT_HIP(hipEventRecord(c->ev_fork[(size_t)l], c->stream));
+            GAT_HIP(hipStreamWaitEvent(c->side_stream, c->ev_fork[(size_t)l], 0));
+            GAT_TRY(backward_grad_w(c, l, c->side_stream));
+            GAT_HIP(hipEventRecord(c->ev_join[(size_t)l], c->side_stream));
+            forked[(size_t)l] = 1;
+            GAT_TRY(backward_grad_x(c, l));
+        } else {
+            GAT_TRY(backward_grad_w(c, l, c->stream));
+            GAT_TRY(backward_grad_x(c, l));
+        }
     }
+    for (int l = 0; l < L; ++l)
+        if (forked[(size_t)l]) GAT_HIP(hipStreamWaitEvent(c->stream, c->ev_join[(size_t)l], 0));        // join: the slab reductions follow
     return 0;
 }
 // tail of the packed gradient buffer -> host values (after an all-reduce the sums over shards)
@@ -1290,7 +1372,7 @@ int gat_table(gat_ctx* c, int which, int32_t l, void** d_ptr, int64_t* n_rows, i
     GAT_TRY(check_layer(c, l));
     if (!d_ptr) return fail(GAT_E_INVALID, "null argument");
     if (which == GAT_TABLE_PL) *d_ptr = c->layers[l].PL;
-    else if (which == GAT_TABLE_GPL) *d_ptr = c->gPL;
+    else if (which == GAT_TABLE_GPL) *d_ptr = c->gPL;                 // (the phase API always uses the first pair)
     else return fail(GAT_E_INVALID, "unknown table");
     if (n_rows) *n_rows = c->n_table;
     if (row_floats) *row_floats = which == GAT_TABLE_PL ? c->layers[l].HD * st_bytes(c) / 4 : c->layers[l].HD;

@@ -325,6 +325,56 @@ def test_step_graph_replay_is_bitwise_the_eager_step(pkg, orc):
     assert abs(outs[1][0][0] - ref.loss_sum_f64) / 300 < TOL
 
 
+def test_grad_w_overlap_is_bitwise_the_serial_order(tmp_path):
+    """gat_step / gat_backward run every hidden layer's grad_w on a side stream (second gPL / gPR pair for the odd layers, fork /
+    join events — a fork / join in the captured graph): same kernels on the same operands, so the gradients must be BITWISE those
+    of the one-stream order (GAT_OVERLAP=0), eagerly and under hipGraph replay, with three and four layers (a buffer pair is
+    rewritten two layers later: the join that protects it)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import __graft_entry__ as entry
+        from conftest import small_graph
+        pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
+        rng = np.random.default_rng(11)
+        rp, ci = small_graph(rng, 3000, 40000, hub=(9, 1500), empty=(0, 3))
+        x = rng.standard_normal((3000, 24)).astype(np.float32)
+        lab = rng.integers(0, 5, 3000).astype(np.int32); lab[0] = 4
+        out = {{}}
+        for heads, outdims in (([8, 8, 8], [8, 8, 8]), ([8, 4, 8, 8], [8, 8, 4, 8])):
+            cfg = orc.Config(heads, outdims, 24, 5)
+            W, a, Wo = orc.xavier_params(cfg, 3)
+            for graph in (False, True):
+                ctx = pkg.GatContext(heads, outdims, 24, 5)
+                ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
+                for g, arr in enumerate((W, a, Wo)): ctx.params_set(g, arr)
+                if graph: ctx.step_graph(True)
+                for it in range(4):
+                    ctx.zero_grad(); loss, correct = ctx.step()
+                    out["L%d_g%d_it%d" % (len(heads), graph, it)] = np.concatenate([[loss, correct]] + [ctx.grads_get(g).ravel() for g in range(3)])
+                    ctx.step_sgd(0.01)
+                if not graph:                       # the two-call form takes the same path
+                    ctx.zero_grad(); ctx.forward(); ctx.backward()
+                    out["L%d_fb" % len(heads)] = np.concatenate([ctx.grads_get(g).ravel() for g in range(3)])
+                ctx.close()
+        np.savez(sys.argv[1], **out)
+        print("OK")
+    """)
+    files = []
+    for tag, env in (("serial", {"GAT_OVERLAP": "0"}), ("overlap", {"GAT_OVERLAP": "1"}), ("default", {})):
+        f = str(tmp_path / (tag + ".npz"))
+        out = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+        files.append(np.load(f))
+    assert len(files[0].files) == 18
+    for k in files[0].files:
+        assert np.isfinite(files[0][k]).all() and np.abs(files[0][k]).max() > 0
+        assert np.array_equal(files[0][k], files[1][k]), k
+        assert np.array_equal(files[0][k], files[2][k]), k
+
+
 def test_step_graph_refused_with_timing(pkg):
     ctx = pkg.GatContext([8, 8], [8, 8], 4, 3, collect_timing=True)
     with pytest.raises(pkg.abi.GatError, match="collect_timing"):
