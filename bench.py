@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--gpl-bf16", action="store_true",
                     help="N>1, --comm native: remote gPL partial sums travel as bf16 (GAT_COMM_GPL_BF16; 1e-2 parity mode, NOT the headline).  "
                          "UNVERIFIED over RCCL beyond world 1 (only its host-transport twin is tested at 3 ranks): default off")
+    ap.add_argument("--halo", type=int, default=0, choices=[0, 1, 2],
+                    help="N>1, --comm native: table exchanges move only the rows the receiving shard's edges reference (gat_comm_option "
+                         "GAT_COMM_HALO; 2 = only if fewer than half of the rows would travel).  Same results as the full exchange.  "
+                         "UNVERIFIED over RCCL beyond world 1: default off")
     ap.add_argument("--beta", type=float, default=0.75, help="power-law exponent of the degree law (debug)")
     ap.add_argument("--sorted-sources", action="store_true",
                     help="experiment, NOT the benchmark graph: source popularity decreasing with the node id (hot table rows adjacent) — "
@@ -266,6 +270,8 @@ def main():
                     ctx.comm_option(A.COMM_PIPELINE, args.comm_chunks)
                 if args.gpl_bf16:
                     ctx.comm_option(A.COMM_GPL_BF16, 1)
+                if args.halo:
+                    ctx.comm_option(A.COMM_HALO, args.halo)
                 runner = ctx
             else:
                 runner = S.ShardedGat(ctx, plan, S.TorchComm(), heads, outdims,
@@ -361,7 +367,8 @@ def main():
                 "parallelism": (f"dst-range x{world}, " + ("all layers exchanged" if args.exchange_layer0 else
                                 "input features replicated (layer 0 exchange-free)") + f", exchanges: {comm_kind}"
                                 + (f", forward exchange pipelined in {args.comm_chunks} chunks" if args.comm_chunks > 1 else "")
-                                + (", remote gPL partials as bf16" if args.gpl_bf16 else ""))
+                                + (", remote gPL partials as bf16" if args.gpl_bf16 else "")
+                                + (f", halo exchange (active={ctx.comm_halo_info()[0]}, referenced fraction {ctx.comm_halo_info()[3]:.3f})" if args.halo and comm_kind == "native" else ""))
                                if runner is not None else "single GPU",
                 "loss_per_node": loss / n, "setup_s": round(t_gen, 1), "index_s": round(t_up, 2),
                 "generator": "device (csrc/gat_synth.hip), bit-for-bit synth.py" + (" — EXPERIMENT: sources sorted by popularity" if args.sorted_sources else ""),

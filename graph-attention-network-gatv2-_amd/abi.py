@@ -50,6 +50,7 @@ PARAM_W, PARAM_A, PARAM_WO = 0, 1, 2
 TABLE_PL, TABLE_GPL = 0, 1
 COMM_GPL_BF16 = 1
 COMM_PIPELINE = 2
+COMM_HALO = 3
 (TAP_SRC, TAP_DST, TAP_ALPHA, TAP_HPRE, TAP_HOUT, TAP_Y, TAP_G, TAP_GE, TAP_MAX, TAP_SUM, TAP_PL,
  TAP_PR, TAP_SCORE, TAP_GALPHA, TAP_GX) = range(15)
 (K_PROJECT, K_EDGE_FWD, K_HEAD_FWD, K_HEAD_BWD, K_EDGE_BWD, K_GPL_SUM, K_GRAD_W, K_GRAD_X, K_MISC,
@@ -132,6 +133,7 @@ def _declare(lib: C.CDLL) -> None:
         "gat_comm_init_rccl": [vp, i32, i32, vp],
         "gat_comm_init_host": [vp, i32, i32, C.c_char_p, i64],
         "gat_comm_option": [vp, i32, i32],
+        "gat_comm_halo_info": [vp, P(i32), P(i64), P(i64), P(C.c_double)],
         "gat_step": [vp, P(f32), P(i32)],
         "gat_step_graph": [vp, i32],
         "gat_forward": [vp, P(f32), P(i32)],
@@ -391,6 +393,12 @@ class GatContext:
 
     def comm_option(self, option: int, value: int):
         _chk(self.lib.gat_comm_option(self._ctx, option, value))
+
+    def comm_halo_info(self):
+        """(active, rows received, rows sent, referenced fraction) of GAT_COMM_HALO."""
+        act, rr, rs, fr = C.c_int32(), C.c_int64(), C.c_int64(), C.c_double()
+        _chk(self.lib.gat_comm_halo_info(self._ctx, C.byref(act), C.byref(rr), C.byref(rs), C.byref(fr)))
+        return bool(act.value), rr.value, rs.value, fr.value
 
     def zero_grad(self):
         _chk(self.lib.gat_zero_grad(self._ctx))

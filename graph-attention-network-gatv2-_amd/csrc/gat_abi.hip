@@ -120,6 +120,8 @@ struct gat_ctx {
     hipStream_t comm_stream = nullptr;              // second stream of the pipelined exchange (created on first use)
     std::vector<hipEvent_t> comm_events;
     bool comm_gpl_bf16 = false;                     // gat_comm_option(GAT_COMM_GPL_BF16): remote gPL partials travel as bf16
+    gat::HaloPlan halo;                             // gat_comm_option(GAT_COMM_HALO): rows each peer's edges reference (built collectively)
+    bool halo_on = false;                           // the table exchanges use it
     float* grads_prev = nullptr;                    // [n_params] with a transport: what the buffer held before this step (see reduce_begin)
     // gat_step as a replayed hipGraph (gat_step_graph): 0 off, 1 armed (next step runs eagerly, then captures), 2 ready
     int graph_state = 0, graph_warm = 0;
@@ -477,6 +479,7 @@ int gat_destroy(gat_ctx* c) {
     for (auto& p : c->ev_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto& p : c->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     c->comm.reset();
+    halo_free(&c->halo);
     for (hipEvent_t e : c->comm_events) (void)hipEventDestroy(e);
     if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
     for (hipEvent_t e : c->ev_fork) (void)hipEventDestroy(e);
@@ -961,7 +964,7 @@ static int forward_phases(gat_ctx* c, int l_end = -1, bool last_edges = true) {
         const bool edges = last_edges || l < l_end - 1;
         // the chunked projection runs the streaming kernel; a layer whose one-launch projection takes the split-K kernel
         // (few rows, F > 128: another summation order) keeps the plain exchange, so that K chunks stay bitwise K = 1
-        if (c->comm && needs_exchange(c, l) && c->comm_chunks > 1 &&
+        if (c->comm && needs_exchange(c, l) && c->comm_chunks > 1 && !c->halo_on &&
             project_scratch_floats(c->n_rows, c->layers[l].F, c->layers[l].HD, kPartBoth) == 0) {
             GAT_TRY(check_layer(c, l));
             GAT_TRY(forward_exchange_pipelined(c, l));
@@ -971,7 +974,8 @@ static int forward_phases(gat_ctx* c, int l_end = -1, bool last_edges = true) {
         GAT_TRY(gat_layer_project(c, l));
         if (c->comm && needs_exchange(c, l)) {
             Scope t(c, GAT_K_EXCHANGE);
-            GAT_TRY(c->comm->all_gather(c->layers[l].PL, pl_slice(c, c->layers[l]), c->stream));
+            if (c->halo_on) GAT_TRY(halo_forward(c->comm.get(), c->halo, c->layers[l].PL, c->layers[l].HD * st_bytes(c) / 4, c->stream));
+            else GAT_TRY(c->comm->all_gather(c->layers[l].PL, pl_slice(c, c->layers[l]), c->stream));
         }
         if (edges) GAT_TRY(gat_layer_forward_edges(c, l));
     }
@@ -1119,7 +1123,8 @@ static int backward_phases(gat_ctx* c, bool head_done = false, bool last_edges_d
         if (!(last_edges_done && l == L - 1)) GAT_TRY(gat_layer_backward_edges(c, l));
         if (c->comm && needs_exchange(c, l)) {
             Scope t(c, GAT_K_EXCHANGE);
-            if (c->comm_gpl_bf16) GAT_TRY(c->comm->reduce_scatter_bf16(gPL_of(c, l), table_slice(c, c->layers[l]), c->stream));
+            if (c->halo_on) GAT_TRY(halo_backward(c->comm.get(), c->halo, gPL_of(c, l), c->layers[l].HD, c->stream));
+            else if (c->comm_gpl_bf16) GAT_TRY(c->comm->reduce_scatter_bf16(gPL_of(c, l), table_slice(c, c->layers[l]), c->stream));
             else GAT_TRY(c->comm->reduce_scatter(gPL_of(c, l), table_slice(c, c->layers[l]), c->stream));
         }
         if (ov && l > 0) {                                            // layer 0's grad_w is the last kernel: nothing to hide behind
@@ -1326,13 +1331,38 @@ int gat_comm_init_host(gat_ctx* c, int32_t world, int32_t rank, const char* shm_
 }
 int gat_comm_option(gat_ctx* c, int32_t option, int32_t value) {
     if (!c) return fail(GAT_E_INVALID, "null context");
-    if (option == GAT_COMM_GPL_BF16) { c->comm_gpl_bf16 = value != 0; return 0; }
+    if (option == GAT_COMM_GPL_BF16) {
+        if (value != 0 && c->halo_on) return fail(GAT_E_UNSUPPORTED, "gat_comm_option: GAT_COMM_GPL_BF16 and GAT_COMM_HALO exclude each other (the halo backward travels as fp32)");
+        c->comm_gpl_bf16 = value != 0;
+        return 0;
+    }
+    if (option == GAT_COMM_HALO) {                       // collective: every rank of the transport makes the same call
+        if (value < 0 || value > 2) return fail(GAT_E_INVALID, "gat_comm_option: GAT_COMM_HALO takes 0 (off), 1 (on) or 2 (on where it pays)");
+        c->halo_on = false;
+        if (value == 0) { halo_free(&c->halo); return 0; }
+        if (!c->comm) return fail(GAT_E_STATE, "gat_comm_option: GAT_COMM_HALO needs a transport (gat_comm_init_*) first");
+        if (c->comm_gpl_bf16) return fail(GAT_E_UNSUPPORTED, "gat_comm_option: GAT_COMM_GPL_BF16 and GAT_COMM_HALO exclude each other");
+        if (c->HDmax % 2 != 0 && bf16(c)) return fail(GAT_E_UNSUPPORTED, "gat_comm_option: GAT_COMM_HALO with bf16 rows needs an even H*D");
+        GAT_TRY(halo_build(c->comm.get(), c->col_idx, c->n_edges, c->n_table, c->HDmax, &c->halo, c->stream));
+        // value 2: only where fewer than half of the rows would travel — a halo costs a pack and an unpack pass over the rows it moves
+        // on each side (4 row transfers through HBM at ~5 TB/s against one over ~1 TB/s of xGMI links: break-even near 0.5)
+        c->halo_on = value == 1 || c->halo.referenced_fraction < 0.5;
+        return 0;
+    }
     if (option == GAT_COMM_PIPELINE) {
         if (value < 1 || value > 64) return fail(GAT_E_INVALID, "gat_comm_option: GAT_COMM_PIPELINE takes 1..64 chunks");
         c->comm_chunks = value;
         return 0;
     }
     return fail(GAT_E_INVALID, "gat_comm_option: unknown option");
+}
+int gat_comm_halo_info(gat_ctx* c, int32_t* active, int64_t* rows_received, int64_t* rows_sent, double* referenced_fraction) {
+    if (!c) return fail(GAT_E_INVALID, "null context");
+    if (active) *active = c->halo_on ? 1 : 0;
+    if (rows_received) *rows_received = c->halo.n_need;
+    if (rows_sent) *rows_sent = c->halo.n_send;
+    if (referenced_fraction) *referenced_fraction = c->halo.world > 0 ? c->halo.referenced_fraction : 1.0;
+    return 0;
 }
 int gat_zero_grad(gat_ctx* c) {
     if (!c) return fail(GAT_E_INVALID, "null context");

@@ -153,6 +153,17 @@ struct RcclComm final : Comm {
         GAT_NCCL(api, api->AllReduce(buf, buf, (size_t)n, kNcclFloat32, kNcclSum, comm, s));
         return 0;
     }
+    int exchange_rows(const float* sendbuf, const int64_t* cnt_send, float* recvbuf, const int64_t* cnt_recv, int64_t rf, hipStream_t s) override {
+        int64_t off_s = 0, off_r = 0;
+        GAT_NCCL(api, api->GroupStart());
+        for (int q = 0; q < world; ++q) {          // (world 1: the self pair, so that the path runs on a one-GPU box)
+            if (cnt_send[q] > 0) GAT_NCCL(api, api->Send(sendbuf + off_s * rf, (size_t)(cnt_send[q] * rf), kNcclFloat32, q, comm, s));
+            if (cnt_recv[q] > 0) GAT_NCCL(api, api->Recv(recvbuf + off_r * rf, (size_t)(cnt_recv[q] * rf), kNcclFloat32, q, comm, s));
+            off_s += cnt_send[q]; off_r += cnt_recv[q];
+        }
+        GAT_NCCL(api, api->GroupEnd());
+        return 0;
+    }
     // bf16 travel format: one point-to-point send + receive per peer (xGMI is a full mesh: every pair has its own link),
     // bytes typed as int8 so that no RCCL reduction is involved; the fp32 sum happens on arrival (sum_arrivals_kernel)
     uint16_t* stage = nullptr; int64_t stage_elems = 0;           // [2][world][slice]: packed outgoing table | arrivals
@@ -320,6 +331,32 @@ struct HostComm final : Comm {
             tmp[(size_t)i] = acc;
         }
         GAT_HIP(hipMemcpyAsync(table + (int64_t)rank * slice, tmp.data(), (size_t)slice * sizeof(float), hipMemcpyHostToDevice, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        return meet();
+    }
+    // packed rows: every rank publishes [world] block offsets (in floats) followed by its send buffer; a receiver copies
+    // the block addressed to it out of each peer's area
+    int exchange_rows(const float* sendbuf, const int64_t* cnt_send, float* recvbuf, const int64_t* cnt_recv, int64_t rf, hipStream_t s) override {
+        const int64_t hdr = ((int64_t)world * 2 + 15) / 16 * 16;           // header floats (int64 offsets), 64-byte aligned
+        int64_t total = 0;
+        for (int q = 0; q < world; ++q) total += cnt_send[q] * rf;
+        GAT_TRY(fits(hdr + total));
+        int64_t* offs = reinterpret_cast<int64_t*>(area(rank));
+        int64_t o = 0;
+        for (int q = 0; q < world; ++q) { offs[q] = o; o += cnt_send[q] * rf; }
+        if (total > 0) GAT_HIP(hipMemcpyAsync(area(rank) + hdr, sendbuf, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s));
+        GAT_HIP(hipStreamSynchronize(s));
+        GAT_TRY(meet());
+        int64_t off_r = 0;
+        for (int p = 0; p < world; ++p) {
+            if (cnt_recv[p] > 0) {
+                const int64_t po = reinterpret_cast<const int64_t*>(area(p))[rank];
+                if (po < 0 || (hdr + po + cnt_recv[p] * rf) * (int64_t)sizeof(float) > bytes_per_rank)
+                    return fail(GAT_E_COMM, "host transport: a peer's block offset is outside its area (mismatched halo plans)");
+                GAT_HIP(hipMemcpyAsync(recvbuf + off_r * rf, area(p) + hdr + po, (size_t)(cnt_recv[p] * rf) * sizeof(float), hipMemcpyHostToDevice, s));
+            }
+            off_r += cnt_recv[p];
+        }
         GAT_HIP(hipStreamSynchronize(s));
         return meet();
     }

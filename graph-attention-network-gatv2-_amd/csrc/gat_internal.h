@@ -202,7 +202,27 @@ struct Comm {
     // rank order.  Option GAT_COMM_GPL_BF16; relative error of the summed rows ~ 2^-9 per remote term.
     virtual int reduce_scatter_bf16(float* table, int64_t slice, hipStream_t s) = 0;
     virtual int all_reduce(float* buf, int64_t n, hipStream_t s) = 0;
+    // Pairwise exchange of packed rows (halo form, gat_halo.hip): this rank sends cnt_send[q] rows of rf floats to every rank q
+    // (sendbuf grouped by q, ascending) and receives cnt_recv[q] rows from it (recvbuf grouped the same way); the counts (host
+    // arrays of `world` entries) are fixed at set-up and consistent between the two ends.  One send / receive pair per peer.
+    virtual int exchange_rows(const float* sendbuf, const int64_t* cnt_send, float* recvbuf, const int64_t* cnt_recv, int64_t rf, hipStream_t s) = 0;
 };
+// Halo form of the table exchanges (gat_halo.hip): per peer, the rows of its slice this shard's edges reference.
+struct HaloPlan {
+    int world = 0, rank = 0;
+    int64_t max_rows = 0;
+    std::vector<int64_t> need_cnt, send_cnt;      // [world] rows received from / sent to each rank in the forward exchange
+    int64_t n_need = 0, n_send = 0, buf_rows = 0;
+    int32_t* need_rows = nullptr;                 // device [n_need] table rows, grouped by owner (ascending)
+    int32_t* send_rows = nullptr;                 // device [n_send] rows of the own slice (local ids), grouped by requester (ascending)
+    int32_t *arr_ptr = nullptr, *arr_split = nullptr, *arr_pos = nullptr;      // backward sum: arrivals per own row, lower ranks first
+    float *sendbuf = nullptr, *recvbuf = nullptr; // [buf_rows][max H*D]
+    double referenced_fraction = 1.0;             // rows on the wire / rows of the full exchange, over all ranks
+};
+int halo_build(Comm* comm, const int32_t* d_col_idx, int64_t n_edges, int64_t n_table, int32_t hd_max, HaloPlan* out, hipStream_t s);
+int halo_forward(Comm* comm, const HaloPlan& h, float* table, int64_t rf, hipStream_t s);
+int halo_backward(Comm* comm, const HaloPlan& h, float* gPL, int64_t rf, hipStream_t s);
+void halo_free(HaloPlan* h);
 int comm_unique_id(void* id_out);
 int comm_create_rccl(int world, int rank, const void* id_bytes, Comm** out);
 int comm_create_host(int world, int rank, const char* shm_name, int64_t bytes_per_rank, Comm** out);

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GAT_ABI_VERSION 5
+#define GAT_ABI_VERSION 6
 
 enum {
     GAT_OK = 0,
@@ -188,9 +188,18 @@ int gat_comm_init_host(gat_ctx* ctx, int32_t world, int32_t rank, const char* sh
  *   Default 0 (fp32 on the wire).  Gradients then differ from the fp32 exchange by ~2^-9 relative per remote term: the
  *   parity bar of this mode is 1e-2 (like bf16 storage).
  *   GAT_COMM_PIPELINE = K (1..64, default 1): the forward exchange of a layer runs in K row chunks on a second stream,
- *   chunk k travelling while chunk k+1 is projected; results are bitwise those of K = 1. */
-enum { GAT_COMM_GPL_BF16 = 1, GAT_COMM_PIPELINE = 2 };
+ *   chunk k travelling while chunk k+1 is projected; results are bitwise those of K = 1.
+ *   GAT_COMM_HALO = 0 | 1 | 2 (default 0): the table exchanges move only the rows the receiving shard's edges reference
+ *   (the rows the reference reads per edge, E:287-290 / E:407-409, and adds into, E:868-869) instead of whole slices: per
+ *   peer one packed send / receive pair forward, its mirror backward, the own slice summed in ascending rank order.  1 = on,
+ *   2 = on if fewer than half of the rows of a full exchange would travel (a halo costs a pack and an unpack pass on each side).
+ *   COLLECTIVE: every rank of the transport makes the call (the request lists are exchanged once, here).  Results equal those of
+ *   the full exchange value for value on the host transport; excludes GAT_COMM_GPL_BF16; GAT_COMM_PIPELINE is ignored while on. */
+enum { GAT_COMM_GPL_BF16 = 1, GAT_COMM_PIPELINE = 2, GAT_COMM_HALO = 3 };
 int gat_comm_option(gat_ctx* ctx, int32_t option, int32_t value);
+/* What GAT_COMM_HALO set up: active (0/1), rows this rank receives / sends per forward table exchange (the backward is the mirror),
+ * and rows on the wire / rows of the full exchange over all ranks (1.0 before the option was ever set).  Any pointer may be NULL. */
+int gat_comm_halo_info(gat_ctx* ctx, int32_t* active, int64_t* rows_received, int64_t* rows_sent, double* referenced_fraction);
 /* forward + backward without a host round-trip in between; with a transport the loss and #correct
  * ride in the tail of the gradient all-reduce.  Returns the global loss sum / #correct. */
 int gat_step(gat_ctx* ctx, float* loss_sum, int32_t* n_correct);

@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(names) >= 40
     for n in names:
         assert hasattr(lib, n), f"{n} declared in gatv2_abi.h but not exported"
-    assert lib.gat_abi_version() == 5
+    assert lib.gat_abi_version() == 6
 
 
 def test_code_object_is_gfx950_only(pkg):

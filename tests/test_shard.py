@@ -380,6 +380,16 @@ def test_library_transport_rccl_world1(pkg, orc):
     loss_p, correct_p = ctx.step()
     assert (loss_p, correct_p) == (loss, correct)
     assert np.array_equal(np.concatenate([ctx.grads_get(g) for g in range(3)]), grads)
+    # the halo form through RCCL's grouped send / receive (world 1: a self exchange of the referenced rows; nothing is summed)
+    ctx.comm_option(pkg.abi.COMM_PIPELINE, 1); ctx.comm_option(pkg.abi.COMM_HALO, 1)
+    act, n_recv, n_sent, frac = ctx.comm_halo_info()
+    assert act and n_recv == n_sent == len(np.unique(P["ci"])) and 0 < frac <= 1
+    ctx.zero_grad()
+    loss_h, correct_h = ctx.step()
+    assert (loss_h, correct_h) == (loss, correct)
+    assert np.array_equal(np.concatenate([ctx.grads_get(g) for g in range(3)]), grads)
+    with pytest.raises(pkg.abi.GatError, match="exclude"):
+        ctx.comm_option(pkg.abi.COMM_GPL_BF16, 1)
     ctx.close()
     assert launches == 2 + 2 + 1             # all-gather and reduce-scatter per layer, one all-reduce
     assert abs(loss - ref.loss_sum_f64) < 1e-4 * P["n"] and correct == ref.n_correct
@@ -481,6 +491,76 @@ def test_bf16_gpl_reduce_scatter_option(pkg):
         parity.check_rel("bf16 gPL exchange vs fp32 exchange", o["g1"], o["g0"], 1e-2)
         assert not np.array_equal(o["g1"], o["g0"])
         assert np.array_equal(o["g1"], outs[0]["g1"])
+
+
+def _halo_worker(rank, world, outdir, shm):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as entry
+    pkg = entry.load_package(); orc = entry.load_oracle()
+    P = _problem(n=900, e=5000)                     # sparse enough that a shard does NOT reference every row of every peer
+    cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
+    W, a, Wo = orc.xavier_params(cfg, 11)
+    S = pkg.shard
+    plan = S.make_plan(P["rp"], world, rank)
+    rp_l, ci_l = S.local_csr(plan, P["rp"], P["ci"])
+    lo, hi = plan.row0, plan.row0 + plan.n_rows
+    out = {}
+    for tag, halo, replicate in (("full", 0, False), ("halo", 1, False), ("auto", 2, False), ("full_rep", 0, True), ("halo_rep", 1, True)):
+        ctx = pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"], device=0)
+        ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
+        if replicate:
+            ctx.set_source_features(plan.table_features(P["x"]))
+        else:
+            ctx.set_features(P["x"][lo:hi])             # layer 0 exchanged too
+        ctx.set_labels(P["lab"][lo:hi])
+        for g, arr in enumerate((W, a, Wo)):
+            ctx.params_set(g, arr)
+        ctx.comm_init_host(world, rank, f"{shm}_{tag}", 4 * max(plan.n_table * 64 + 64, ctx.n_params + 3))
+        if halo:
+            ctx.comm_option(pkg.abi.COMM_HALO, halo)
+        act, n_recv, n_sent, frac = ctx.comm_halo_info()
+        out[f"info_{tag}"] = np.array([act, n_recv, n_sent, frac, (world - 1) * (plan.n_table // world)], np.float64)
+        ctx.zero_grad()
+        loss, correct = ctx.step()
+        out[f"g_{tag}"] = np.concatenate([ctx.grads_get(g) for g in range(3)]); out[f"l_{tag}"] = np.array([loss, correct])
+        ctx.zero_grad(); loss2, correct2 = ctx.forward(); ctx.backward()          # the two-call form takes the same exchanges
+        assert (loss2, correct2) == (loss, correct) and np.array_equal(out[f"g_{tag}"], np.concatenate([ctx.grads_get(g) for g in range(3)]))
+        if halo == 1:
+            # the referenced rows of the forward table are exactly those of the full exchange
+            pl = ctx.tap(pkg.abi.TAP_PL, 1)
+            ref_rows = np.unique(ci_l)
+            out[f"pl_{tag}"] = pl[ref_rows]
+        elif not halo:
+            out[f"pl_{tag}"] = ctx.tap(pkg.abi.TAP_PL, 1)[np.unique(ci_l)]
+        ctx.close()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), **out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_halo_exchange_equals_the_full_exchange(pkg, world):
+    """GAT_COMM_HALO: per peer only the rows this shard's edges reference travel (packed send / receive pairs forward, the
+    mirror backward, the own slice summed in ascending rank order).  Loss, #correct, every gradient and every REFERENCED row of
+    the exchanged table must equal the full all-gather / reduce-scatter value for value on the host transport, with layer 0
+    exchanged or replicated; fewer rows than the full exchange must travel on this sparse graph; value 2 decides by the
+    referenced fraction."""
+    import torch.multiprocessing as mp
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_halo_worker, args=(world, d, f"/gatv2_halo_{os.getpid()}"), nprocs=world, join=True)
+        outs = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
+    sent = sum(int(o["info_halo"][2]) for o in outs); recv = sum(int(o["info_halo"][1]) for o in outs)
+    assert sent == recv and sent > 0
+    for o in outs:
+        for a_, b_ in (("halo", "full"), ("halo_rep", "full_rep")):
+            assert np.array_equal(o[f"l_{a_}"], o[f"l_{b_}"])
+            assert np.array_equal(o[f"g_{a_}"], o[f"g_{b_}"])
+            assert np.array_equal(o[f"pl_{a_}"], o[f"pl_{b_}"])
+        assert np.array_equal(o["g_halo"], outs[0]["g_halo"])              # every rank holds the same reduced gradients
+        assert np.array_equal(o["g_auto"], o["g_full"])
+        act, n_recv, n_sent, frac, full_rows = o["info_halo"]
+        assert act == 1 and 0 < n_recv < full_rows and 0 < frac < 1
+        assert o["info_full"][0] == 0 and o["info_auto"][0] == (1 if o["info_auto"][3] < 0.5 else 0)
+        assert abs(frac - sent / (world * full_rows)) < 1e-12
 
 
 def _pipeline_worker(rank, world, outdir, shm):
