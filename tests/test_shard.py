@@ -524,7 +524,10 @@ def _halo_worker(rank, world, outdir, shm):
         loss, correct = ctx.step()
         out[f"g_{tag}"] = np.concatenate([ctx.grads_get(g) for g in range(3)]); out[f"l_{tag}"] = np.array([loss, correct])
         ctx.zero_grad(); loss2, correct2 = ctx.forward(); ctx.backward()          # the two-call form takes the same exchanges
-        assert (loss2, correct2) == (loss, correct) and np.array_equal(out[f"g_{tag}"], np.concatenate([ctx.grads_get(g) for g in range(3)]))
+        assert correct2 == correct and abs(loss2 - loss) < 1e-5 * max(1.0, abs(loss)), (tag, loss, loss2)
+        g_fb = np.concatenate([ctx.grads_get(g) for g in range(3)])     # (the fused head of gat_step sums grad_Wo in another order: not bitwise)
+        assert np.allclose(out[f"g_{tag}"], g_fb, rtol=1e-5, atol=1e-6 * np.abs(g_fb).max()), tag
+        out[f"gfb_{tag}"] = g_fb
         if halo == 1:
             # the referenced rows of the forward table are exactly those of the full exchange
             pl = ctx.tap(pkg.abi.TAP_PL, 1)
@@ -554,6 +557,7 @@ def test_halo_exchange_equals_the_full_exchange(pkg, world):
         for a_, b_ in (("halo", "full"), ("halo_rep", "full_rep")):
             assert np.array_equal(o[f"l_{a_}"], o[f"l_{b_}"])
             assert np.array_equal(o[f"g_{a_}"], o[f"g_{b_}"])
+            assert np.array_equal(o[f"gfb_{a_}"], o[f"gfb_{b_}"])
             assert np.array_equal(o[f"pl_{a_}"], o[f"pl_{b_}"])
         assert np.array_equal(o["g_halo"], outs[0]["g_halo"])              # every rank holds the same reduced gradients
         assert np.array_equal(o["g_auto"], o["g_full"])
