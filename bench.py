@@ -171,9 +171,15 @@ def measured_traffic(args, world, kernel):
     (profiles/*/traffic.json, collected with tools/pmc_traffic.sh on this workload at N=1; the newest round wins):
     PMC counters cannot be read from inside the benchmark process, so the figure is attached only when workload,
     dtype and scale match, else null."""
+    return measured_traffic_src(args, world, kernel)[0]
+
+
+def measured_traffic_src(args, world, kernel):
+    """(bytes, "profiles/rNN/traffic.json (rocprofv3 PMC, builder-run)") — the figure and the committed file it was read from: it
+    is NOT measured in this run (a reader of the JSON line must be able to tell: VERDICT r3)."""
     if world != 1 or args.scale != 1.0:
-        return None
-    best = None
+        return None, None
+    best, src = None, None
     for path in sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "*", "traffic*.json"))):
         try:
             t = json.load(open(path))
@@ -182,10 +188,13 @@ def measured_traffic(args, world, kernel):
         if t.get("workload") != args.workload or t.get("dtype", "f32") != args.dtype:
             continue
         if kernel is None:
-            best = t.get("bytes_per_step", best)
+            if t.get("bytes_per_step") is not None:
+                best, src = t["bytes_per_step"], path
         elif kernel in t.get("kernels", {}):
-            best = t["kernels"][kernel]["bytes_per_launch"]
-    return best
+            best, src = t["kernels"][kernel]["bytes_per_launch"], path
+    if src is not None:
+        src = os.path.relpath(src, ROOT) + " (rocprofv3 PMC passes run by the builder with tools/pmc_traffic.sh; a committed constant, not measured in this run)"
+    return best, src
 
 
 def main():
@@ -378,13 +387,14 @@ def main():
                               "frac_of_8TBps_per_gpu": bytes_step_all / (dt / args.steps) / 1e9 / world / HBM_PEAK_GBS,
                               # HBM bytes the step really moves (sum of the PMC passes over all its kernels), and its
                               # ratio to the algorithmic bytes: > 1 = traffic the algorithm does not need
-                              "traffic": step_traffic,
+                              "traffic": step_traffic, "traffic_source": measured_traffic_src(args, world, None)[1],
                               "traffic_over_algorithmic": (step_traffic / bytes_step_all) if step_traffic else None,
                               "training_path_GB_per_step": (tp_bytes_step / 1e9) if tp_bytes_step else None,
                               "frac_training_path": (tp_bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if tp_bytes_step else None,
                               "note": pmc_note},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args, world, dom),
+                         "traffic_source": measured_traffic_src(args, world, dom)[1],
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
                          # the kernel's REAL HBM rate (PMC bytes / measured time): what the memory system delivers to it,
                          # whatever share of those bytes the algorithm needs

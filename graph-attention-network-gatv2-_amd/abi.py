@@ -77,9 +77,12 @@ def load_library(preload_torch: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # GATV2_LIB: another build of the same ABI — the experiment library (csrc `make experiments`, libgatv2_hip_exp.so: the
+    # timing-only GAT_DBG variants live only there) for tools/bench_ab.sh and the experiment-kernel tests
+    lib_path = os.environ.get("GATV2_LIB") or LIB_PATH
+    if not os.path.exists(lib_path):
         raise GatLibraryError(
-            f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{lib_path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the HIP path)")
     if preload_torch:
         try:
@@ -87,12 +90,19 @@ def load_library(preload_torch: bool = True) -> C.CDLL:
         except Exception:  # torch absent: fall back to the system HIP runtime
             pass
     try:
-        lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
+        lib = C.CDLL(lib_path, mode=C.RTLD_LOCAL)
     except OSError as e:
-        raise GatLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        raise GatLibraryError(f"cannot load {lib_path}: {e}") from e
     _declare(lib)
     _lib = lib
     return lib
+
+
+def switches() -> str:
+    """The choice switches (environment) this process has read and found set: "NAME=VALUE ..." (gat_switches)."""
+    buf = C.create_string_buffer(4096)
+    _chk(load_library().gat_switches(buf, 4096))
+    return buf.value.decode()
 
 
 def _declare(lib: C.CDLL) -> None:
@@ -105,6 +115,7 @@ def _declare(lib: C.CDLL) -> None:
     sigs = {
         "gat_abi_version": [],
         "gat_device_count": [P(C.c_int)],
+        "gat_switches": [C.c_char_p, i64],
         "gat_create": [P(_Config), P(vp)],
         "gat_destroy": [vp],
         "gat_sync": [vp],

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 namespace gat {
 
@@ -17,6 +18,26 @@ void set_error(const std::string& msg) { g_err = msg; }
 int fail(int code, const std::string& msg) {
     g_err = msg;
     return code ? code : GAT_E_INVALID;
+}
+// Choice switches: environment variables that select among kernels / launch shapes computing the SAME results (the test
+// matrices force every one).  Each is read once per process through here, and what was set is reported by gat_switches().
+static std::mutex g_choice_mu;
+static std::vector<std::pair<std::string, std::string>> g_choices;
+const char* choice_env(const char* name) {
+    const char* e = getenv(name);
+    if (e) {
+        std::lock_guard<std::mutex> lock(g_choice_mu);
+        bool seen = false;
+        for (auto& kv : g_choices) if (kv.first == name) { kv.second = e; seen = true; }
+        if (!seen) g_choices.emplace_back(name, e);
+    }
+    return e;
+}
+static std::string choices_text() {
+    std::lock_guard<std::mutex> lock(g_choice_mu);
+    std::string t;
+    for (auto& kv : g_choices) { if (!t.empty()) t += ' '; t += kv.first + "=" + kv.second; }
+    return t;
 }
 
 struct Layer {
@@ -40,7 +61,7 @@ struct Layer {
 struct Pending { int k; hipEvent_t e0, e1; };
 
 void build_worklist(const int32_t* rp, int64_t n_rows, WorkList& w) {
-    static const int seg_env = [] { const char* e = getenv("GAT_SEG_EDGES"); const int v = e ? atoi(e) : 0; return v >= 16 ? v : 0; }();
+    static const int seg_env = [] { const char* e = choice_env("GAT_SEG_EDGES"); const int v = e ? atoi(e) : 0; return v >= 16 ? v : 0; }();
     // GAT_SEG_EDGES=<n>: sweep of the hub-row segment length.  Default 256 (swept on the Products shape); graphs with
     // few edges get shorter segments: the persistent backward's critical path is its longest item (a 256-edge segment
     // is 64 dependent gather steps), which at Arxiv size (1.17 M edges) was longer than everything else together
@@ -70,7 +91,7 @@ void build_worklist(const int32_t* rp, int64_t n_rows, WorkList& w) {
     // stay near each other).  GAT_SORT_WINDOW rows per window, 0 = one window over all rows; swept on the Products
     // shape: 4096 and one window are within noise for the backward, 4096 is ~3 % better for the forward.
     {
-        static const int64_t win_env = [] { const char* e = getenv("GAT_SORT_WINDOW"); return e ? atoll(e) : (int64_t)-1; }();
+        static const int64_t win_env = [] { const char* e = choice_env("GAT_SORT_WINDOW"); return e ? atoll(e) : (int64_t)-1; }();
         const int64_t win = win_env < 0 ? 4096 : (win_env == 0 ? n_rows : win_env);
         std::vector<int64_t> cnt((size_t)kSegEdges + 2);
         for (int64_t r0 = 0; r0 < n_rows; r0 += win) {
@@ -299,7 +320,7 @@ static int ensure_buffers(gat_ctx* c) {
     // the source-major pass) where the shape has one, else H*D-float message rows.  GAT_BWD_STASH=0 forces message
     // rows everywhere (the A/B of DESIGN §4); the taps variant of the backward always uses message rows.
     int32_t msg_hd = 0, stash_words = 0;
-    const char* no_stash = getenv("GAT_BWD_STASH");
+    const char* no_stash = choice_env("GAT_BWD_STASH");
     for (int l = 0; l < L; ++l) {
         Layer& y = c->layers[l];
         if (!edge_fast_path(y.H, y.D, c->n_table)) continue;
@@ -310,7 +331,7 @@ static int ensure_buffers(gat_ctx* c) {
         y.stash = w > 0 && !c->cfg.keep_taps && !(no_stash && no_stash[0] == '0') && !(bf16(c) && y.HD < 64);
         if (y.stash) stash_words = std::max(stash_words, w); else msg_hd = std::max(msg_hd, y.HD);
     }
-    const char* force = getenv("GAT_BWD_ATOMICS");
+    const char* force = choice_env("GAT_BWD_ATOMICS");
     if ((msg_hd > 0 || stash_words > 0) && E > 0 && !(force && force[0] == '1')) {
         float* m = nullptr;
         // E + 1 rows / records: the last one takes the stores of the group-per-row kernels' padded lanes; kPullPad records of
@@ -331,7 +352,7 @@ static int ensure_buffers(gat_ctx* c) {
             GAT_TRY(dalloc(c, &c->csc_ptr, T + 1));
             // slot-parallel source-major pass (gat_csc.hip "runs"): the source of every slot + the lists crossing a run boundary.
             // GAT_PULL_RUN=<slots per run> (a multiple of 32; 0 = do not build)
-            static const int run_env = [] { const char* e = getenv("GAT_PULL_RUN"); return e ? atoi(e) : -1; }();
+            static const int run_env = [] { const char* e = choice_env("GAT_PULL_RUN"); return e ? atoi(e) : -1; }();
             const int32_t run = run_env >= 0 ? (run_env / 32) * 32 : 64;
             if (run > 0) GAT_TRY(dalloc(c, &c->csc_src, E + kPullPad));
             GAT_TRY(build_csc(c->col_idx, E, T, c->csc_pos, c->csc_ptr, c->csc_src, c->stream));
@@ -399,12 +420,14 @@ static int ensure_buffers(gat_ctx* c) {
     // The cliff of gatv2_abi.h "Limits": a layer whose SHAPE has wave-per-row kernels but whose gathered table is 4 GiB or
     // more drops to the generic float-atomic kernels.  Not an error (same results) — but never silent: the call that
     // completed the context returns 0 with this text in gat_last_error(), and gat_layer_path() reports it per layer.
+    std::string slow;
     for (int l = 0; l < L; ++l) {
         const Layer& y = c->layers[l];
-        if (!edge_fast_path(y.H, y.D, T) && edge_fast_path(y.H, y.D, 1))
-            set_error("warning: layer " + std::to_string(l) + ": source table of " + std::to_string(T) + " rows x " + std::to_string(y.HD) +
-                      " floats is >= 4 GiB — this layer runs on the generic float-atomic kernels (several times slower); shard the graph by destination range to stay on the wave-per-row path");
+        if (!edge_fast_path(y.H, y.D, T) && edge_fast_path(y.H, y.D, 1)) slow += (slow.empty() ? "" : ", ") + std::to_string(l) + " (H*D = " + std::to_string(y.HD) + ")";
     }
+    if (!slow.empty())
+        set_error("warning: layer(s) " + slow + ": source table of " + std::to_string(T) + " rows is >= 4 GiB — these layers run on the generic "
+                  "float-atomic kernels (several times slower); shard the graph by destination range to stay on the wave-per-row path (gat_layer_path reports it per layer)");
     return 0;
 }
 
@@ -416,6 +439,16 @@ extern "C" {
 
 const char* gat_last_error(void) { return g_err.c_str(); }
 int gat_abi_version(void) { return GAT_ABI_VERSION; }
+int gat_switches(char* buf, int64_t cap) {
+    if (!buf || cap <= 0) return fail(GAT_E_INVALID, "gat_switches: null buffer");
+    std::string t = choices_text();
+#ifdef GAT_EXPERIMENTS
+    t = t.empty() ? "[experiment library]" : "[experiment library] " + t;
+#endif
+    if ((int64_t)t.size() + 1 > cap) return fail(GAT_E_INVALID, "gat_switches: buffer too small");
+    memcpy(buf, t.c_str(), t.size() + 1);
+    return 0;
+}
 int gat_device_count(int* count) {
     if (!count) return fail(GAT_E_INVALID, "null count");
     GAT_HIP(hipGetDeviceCount(count));
@@ -459,7 +492,9 @@ int gat_create(const gat_config* cfg, gat_ctx** out) {
     c->nWo = (int64_t)cfg->num_classes * c->layers.back().D;
     if (cfg->storage_dtype != GAT_DTYPE_F32 && cfg->storage_dtype != GAT_DTYPE_BF16)
         return fail(GAT_E_INVALID, "storage_dtype must be GAT_DTYPE_F32 or GAT_DTYPE_BF16");
+#ifdef GAT_EXPERIMENTS                               // the release library does not know the name: a stray variable cannot change results
     if (const char* d = getenv("GAT_DBG")) c->dbg = atoi(d);
+#endif
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { GAT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     gat_ctx* p = c.get();
@@ -831,7 +866,7 @@ static int plan_backward_edges(gat_ctx* c, int32_t l, BwdPlan* P) {
     // last layer: the pull pass rebuilds g from gH and the decision bytes (GAT_PULL_LAST=0: gathers gfull like a hidden layer, A/B)
     // Worth it only when the g rows the pull pass would gather do not stay in the caches (Products shape 627 MB: 2.73 -> 2.29 ms;
     // Arxiv shape 43 MB: the extra loads per slot cost more than the smaller rows save, 1.31 -> 1.25 ms per step without)
-    static const int pull_last = [] { const char* e = getenv("GAT_PULL_LAST"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    static const int pull_last = [] { const char* e = choice_env("GAT_PULL_LAST"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     // With the slot-parallel pull pass (short lists: shards) the records pay from 64 MB of g rows on: one cache line per slot instead
     // of two, and that pass is bound by lines per second (Products P = 8 shard, 78 MB: 0.84 -> 0.78 ms per step; Arxiv 43 MB: equal)
     const bool runs_form = c->runs.csrc != nullptr && c->n_edges < 8 * c->n_table && c->n_edges >= ((int64_t)512 << 10);
@@ -857,7 +892,7 @@ static int sum_backward_edges(gat_ctx* c, int32_t l, const BwdPlan& P) {
         return launch_gpl_pull(c->csc_ptr, c->stash, c->csc_dst, c->gfull, bf16(c), P.last_g ? c->gH : nullptr, P.last_g ? c->hbits : nullptr, c->gh_stride, 64,
                                a_of(c, l), c->cfg.negative_slope, gPL_of(c, l), c->n_table,
                                c->n_edges, y.H, y.D, c->gpl_chunks, c->n_gpl_chunks, c->gpl_heavy, c->n_gpl_heavy, c->gpl_part,
-                               c->pull_items, c->n_pull_items, c->runs.csrc ? &c->runs : nullptr, c->stream);
+                               c->pull_items, c->n_pull_items, c->runs.csrc ? &c->runs : nullptr, c->n_edges + kPullPad, c->stream);
     }
     if (P.store) {
         Scope t(c, GAT_K_GPL_SUM);
@@ -1018,7 +1053,7 @@ static bool fused_last(gat_ctx* c) {
     // MEASURED, NOT THE DEFAULT (DESIGN §4 "Round 3"): on the Products shape the fused launch takes 5.0 ms for the 76 % of the edges
     // that sit in unsplit rows — what the separate forward + backward take for them — and the split rows' segments, launched on
     // their own, lose what they used to hide behind the bulk: 20.95 vs 20.78 ms per step.  GAT_FUSE_LAST=1 enables.
-    static const int env = [] { const char* e = getenv("GAT_FUSE_LAST"); return e ? (e[0] == '0' ? 0 : 1) : 0; }();
+    static const int env = [] { const char* e = choice_env("GAT_FUSE_LAST"); return e ? (e[0] == '0' ? 0 : 1) : 0; }();
     return env == 1;
 }
 static int last_layer_fused(gat_ctx* c) {
@@ -1052,7 +1087,7 @@ static int last_layer_fused(gat_ctx* c) {
     EdgeLastArgs a{};
     a.f = f; a.f.items = c->items + n_seg; a.f.n_items = c->work.n_items - n_seg;
     float* ga_b = ga_a + (int64_t)blocks_a * y.HD;
-    a.b = P.a; a.b.ga_partial = ga_b; a.b.ga_blocks = a.f.n_items > 0 ? edge_last_fused_blocks(a.f.n_items) : 0;
+    a.b = P.a; a.b.ga_partial = ga_b; a.b.ga_blocks = a.f.n_items > 0 ? std::min(edge_last_fused_blocks(a.f.n_items), 2048 - blocks_a) : 0;    // the layer's region holds 2048 partial rows
     a.Wo = Wo_of(c); a.labels = c->labels_eff ? c->labels_eff : c->labels; a.gh_out = c->gH; a.C = c->cfg.num_classes;
     {
         Scope t(c, GAT_K_EDGE_FUSED);
@@ -1076,7 +1111,7 @@ static int last_layer_fused(gat_ctx* c) {
 // or a replicated layer-0 input (its two grad_w launches share one slab region).  Same kernels, same operands: bitwise the
 // serial order's gradients.  Captured by gat_step_graph as a fork / join in the graph.
 static int overlap_prepare(gat_ctx* c) {
-    static const int env = [] { const char* e = getenv("GAT_OVERLAP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    static const int env = [] { const char* e = choice_env("GAT_OVERLAP"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     const int L = c->cfg.num_layers;
     const bool want = env == 1;
     if (!want || L < 2 || c->gPL_bound || c->Xtab) return 0;
@@ -1089,7 +1124,7 @@ static int overlap_prepare(gat_ctx* c) {
         {   // lowest priority: grad_w should fill what the edge passes leave free (their tails), not take their wave slots
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            static const bool prio = [] { const char* e = getenv("GAT_OVERLAP_PRIO"); return !(e && e[0] == '0'); }();
+            static const bool prio = [] { const char* e = choice_env("GAT_OVERLAP_PRIO"); return !(e && e[0] == '0'); }();
             if (prio) GAT_HIP(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, least));
             else GAT_HIP(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
         }
@@ -1193,7 +1228,7 @@ static int reduce_end(gat_ctx* c, int64_t count) {          // count: n_params, 
 struct BatchScope {
     bool on;
     explicit BatchScope(gat_ctx* c) {
-        static const bool env_on = [] { const char* e = getenv("GAT_REDUCE_BATCH"); return !(e && e[0] == '0'); }();
+        static const bool env_on = [] { const char* e = choice_env("GAT_REDUCE_BATCH"); return !(e && e[0] == '0'); }();
         on = env_on && !c->Xtab;
         if (on) reduce_batch_begin();
     }

@@ -206,7 +206,7 @@ struct ShmHeader {
     int64_t bytes_per_rank;
 };
 static double comm_timeout_s() {   // GAT_COMM_TIMEOUT_S (default 120 s): how long a rank waits for its peers at an exchange
-    static const double v = [] { const char* e = getenv("GAT_COMM_TIMEOUT_S"); const double x = e ? atof(e) : 0.0; return x > 0.0 ? x : 120.0; }();
+    static const double v = [] { const char* e = choice_env("GAT_COMM_TIMEOUT_S"); const double x = e ? atof(e) : 0.0; return x > 0.0 ? x : 120.0; }();
     return v;
 }
 constexpr size_t kShmHeader = 4096;

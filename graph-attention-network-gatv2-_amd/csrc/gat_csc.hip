@@ -48,7 +48,7 @@ constexpr int kHeavySlotsDefault = 512;    // swept on the Products shape: 64..1
 // GAT_GPL_HEAVY=<n> overrides (tests: huge = never chunk).  Graphs with few edges chunk earlier: there the pass is as long
 // as its longest list (a 500-slot list is ~30 dependent gather steps of one wave; Arxiv shape: 0.13 -> 0.05 ms per launch)
 static int heavy_slots(int64_t n_edges) {
-    static const int v = [] { const char* e = getenv("GAT_GPL_HEAVY"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 0; }();
+    static const int v = [] { const char* e = choice_env("GAT_GPL_HEAVY"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 0; }();
     return v ? v : (n_edges < (16 << 20) ? 128 : kHeavySlotsDefault);
 }
 
@@ -989,12 +989,12 @@ int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int
 template <int HD, int N, bool BF, int LASTD>
 static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, const uint8_t* hbits,
                     int gh_stride, int hb_stride, const float* a, float slope, float* gPL, int64_t n_table, const int4* chunks, int32_t n_chunks, const int4* heavy,
-                    int32_t n_heavy, float* part, int wpb, int64_t n_slots, const int4* items, int64_t n_items, const SlotRuns* runs, hipStream_t s) {
+                    int32_t n_heavy, float* part, int wpb, int64_t n_slots, const int4* items, int64_t n_items, const SlotRuns* runs, bool padded, hipStream_t s) {
     // Slot-parallel form (gpl_pull_runs_kernel): default where the lists are short (a destination-range shard: the list-per-group
     // kernel below pays three dependent latencies per ~4 slots); GAT_PULL_RUNS=0|1 forces.  The last layer's variant reads the
     // 64-byte node records (gh_stride 16, decision bytes at +32).
-    static const int runs_env = [] { const char* e = getenv("GAT_PULL_RUNS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    static const int groups_env = [] { const char* e = getenv("GAT_PULL_GROUPS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    static const int runs_env = [] { const char* e = choice_env("GAT_PULL_RUNS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    static const int groups_env = [] { const char* e = choice_env("GAT_PULL_GROUPS"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool runs_ok = runs != nullptr && runs->csrc != nullptr && runs->run % (HD / N) == 0 && (LASTD == 0 || (gh_stride == 16 && hb_stride == 64));
     if (runs_ok && (runs_env >= 0 ? runs_env == 1 : (groups_env < 0 && n_slots < 8 * n_table && n_slots >= kRunsMinSlots))) {     // an explicit GAT_PULL_GROUPS selects among the list kernels
         constexpr int G = 64 / (HD / N), U = (HD / N) % 8 == 0 ? 8 : 4;
@@ -1002,7 +1002,7 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
         rd.csrc = runs->csrc; rd.empty = runs->empty; rd.part = runs->part; rd.n_empty = runs->n_empty; rd.n_slots = n_slots; rd.n_table = n_table;
         rd.run = runs->run; rd.zero_blocks = (int32_t)((runs->n_empty + 4 * G * 8 - 1) / (4 * G * 8));
         const int64_t waves = (runs->n_runs + G - 1) / G, blocks = rd.zero_blocks + (waves + 3) / 4;
-        static const int u_env = [] { const char* e = getenv("GAT_PULL_U"); return e ? atoi(e) : 0; }();      // experiment: slots per batch (16-lane groups)
+        static const int u_env = [] { const char* e = choice_env("GAT_PULL_U"); return e ? atoi(e) : 0; }();      // experiment: slots per batch (16-lane groups)
         if (blocks > 0) {
             if constexpr (HD / N == 16 && !BF) {
                 if (u_env == 4) hipLaunchKernelGGL((gpl_pull_runs_kernel<HD, N, BF, LASTD, 4>), dim3((unsigned)blocks), dim3(256), 0, s, stash, cdst, gfull, hbits, a, slope, gPL, rd);
@@ -1045,9 +1045,9 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
     // busy) and gains from the shorter instruction stream; the hidden layer's is bound by its two-line gathers and loses to the
     // second form's unclamped chunk reads (+8 % record lines).  Default: second form for the last layer only; GAT_PULL_V2 forces
     // one form on both (0 | 1 | 2).
-    static const int v2_env = [] { const char* e = getenv("GAT_PULL_V2"); return e ? atoi(e) : -1; }();
+    static const int v2_env = [] { const char* e = choice_env("GAT_PULL_V2"); return e ? atoi(e) : -1; }();
     const int v2_want = v2_env >= 0 ? v2_env : (LASTD > 0 ? 2 : 0);
-    const int v2 = (!BF && (LASTD == 0 || (gh_stride == 16 && hb_stride == 64))) ? v2_want : 0;
+    const int v2 = (padded && !BF && (LASTD == 0 || (gh_stride == 16 && hb_stride == 64))) ? v2_want : 0;
     const dim3 cgrid((unsigned)((n_chunks + 3) / 4)), pgrid((unsigned)((n_table + wpb - 1) / wpb)), pblock(64 * wpb);
 #define GAT_PULL_LAUNCH(V2_)                                                                                                          \
     do {                                                                                                                              \
@@ -1075,14 +1075,20 @@ static int run_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t
 int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16,
                     const float* gh, const uint8_t* hbits, int32_t gh_stride, int32_t hb_stride, const float* a,
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
-                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, const SlotRuns* runs, hipStream_t s) {
+                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, const SlotRuns* runs,
+                    int64_t slot_capacity, hipStream_t s) {
     if (n_table <= 0) return 0;
+    // the second form of the slot walk and the slot-parallel form read whole 16-slot chunks without clamping: the record buffer and
+    // the destination list must hold kPullPad slots behind the last (gat_internal.h); a caller with exact-size buffers gets the
+    // clamped first form on per-list kernels instead of an out-of-bounds read
+    const bool padded = slot_capacity >= n_slots + kPullPad;
+    if (!padded) runs = nullptr;
     // one wave per block for the pull kernel (GAT_GPL_WAVES=1|2|4): 5.03 / 5.11 / 5.30 ms per step on the Products shape — a
     // 4-wave block lives as long as its longest list; the message-row sum (launch_gpl_sum) measured the other way round
-    static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
+    static const int wpb = [] { const char* e = choice_env("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
     const int HD = H * D;
     const bool last = gh != nullptr && hbits != nullptr;
-#define PULL_ARGS(G_) src_ptr, stash, cdst, G_, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, items, n_items, runs, s
+#define PULL_ARGS(G_) src_ptr, stash, cdst, G_, hbits, gh_stride, hb_stride, a, slope, gPL, n_table, chunks, n_chunks, heavy, n_heavy, part, wpb, n_slots, items, n_items, runs, padded, s
 #define PULL(HD_, N_, D_)                                                                           \
     {                                                                                               \
         if (last) return run_pull<HD_, N_, false, D_>(PULL_ARGS(gh));                               \
@@ -1211,8 +1217,8 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
     // forces.  Not for bf16 rows: a 64-byte row is FOUR lanes, and a segment end is a store instruction of its own per group (two
     // half-line requests per 128-byte gPL row), where the list kernel's 16 groups store 16 consecutive rows with one instruction —
     // BASELINE config 5's P = 8 shard measured 1.49-1.54 ms per step against 1.31 (profiles/r04/experiments)
-    static const int runs_env = [] { const char* e = getenv("GAT_PULL_RUNS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    static const bool group_env = getenv("GAT_GPL_GROUP") != nullptr || getenv("GAT_GPL_BF16_GROUP") != nullptr;
+    static const int runs_env = [] { const char* e = choice_env("GAT_PULL_RUNS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    static const bool group_env = choice_env("GAT_GPL_GROUP") != nullptr || choice_env("GAT_GPL_BF16_GROUP") != nullptr;
     if (runs != nullptr && runs->csrc != nullptr && runs->run % 16 == 0 && (HD == 64 || HD == 32 || HD == 16 || HD == 8) &&
         (runs_env >= 0 ? runs_env == 1 : (!group_env && !msg_bf16 && n_slots < 8 * n_table && n_slots >= kRunsMinSlots))) {
         const int G = 64 / (HD / (msg_bf16 ? 8 : 4));
@@ -1245,10 +1251,10 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
     }
     // waves per block of the per-source kernels (GAT_GPL_WAVES, A/B): unlike the edge forward, 4 beats 1 here
     // (6.15 vs 6.31 ms per step on one box)
-    static const int wpb = [] { const char* e = getenv("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
+    static const int wpb = [] { const char* e = choice_env("GAT_GPL_WAVES"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
     if (msg_bf16) {
         // group per source unless GAT_GPL_BF16_GROUP=0 (A/B): 10 M / 250 M shape, H*D = 32
-        static const bool bgroup = [] { const char* e = getenv("GAT_GPL_BF16_GROUP"); return !(e && e[0] == '0'); }();
+        static const bool bgroup = [] { const char* e = choice_env("GAT_GPL_BF16_GROUP"); return !(e && e[0] == '0'); }();
         if (bgroup) {
             const int rpi = 64 / (HD / 8);
             const dim3 ggrid((unsigned)((n_table + 4 * rpi - 1) / (4 * rpi)));
@@ -1273,7 +1279,7 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
         GAT_HIP(hipGetLastError());
         return 0;
     }
-    static const char* force = getenv("GAT_GPL_GROUP");          // A/B switch: 0 = wave per source, 1 = group per source
+    static const char* force = choice_env("GAT_GPL_GROUP");          // A/B switch: 0 = wave per source, 1 = group per source
     const bool group = force ? force[0] == '1' : n_slots < 8 * n_table;   // measured: 3.2 slots/source 1.24 -> 1.00 ms, 12.6: 3.20 -> 3.31
     if (group && HD >= 8 && HD <= 64) {
         const int rpi = 64 / (HD / 4);

@@ -1431,6 +1431,7 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const int4* __restrict__
     for (int d = 0; d < DLAST; ++d) gh_out[row * gh_stride + d] = acc[d];
 }
 
+#ifdef GAT_EXPERIMENTS      // measured, not ahead (DESIGN §4 "Round 3"): in the experiment library only (make experiments)
 // ------------------------------------------------------------------------------------------------
 // EXPERIMENT (GAT_DBG=4, H*D = 64, D = 8, fp32): wave-specialised record stores.
 // Blocks of NCW compute waves + ONE storing wave.  A compute wave runs the step body of edge_bwd3_kernel but hands the
@@ -1628,6 +1629,8 @@ __global__ __launch_bounds__((NCW + 1) * 64) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+#endif  // GAT_EXPERIMENTS
+
 // gPR of split rows: sum of the row's segment partials in segment order (one thread per channel).
 __global__ __launch_bounds__(256) void edge_bwd_fix_kernel(const int4* __restrict__ slot_info, int32_t n_slots,
                                                           int32_t n_split, const float* __restrict__ part,
@@ -1780,17 +1783,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 template <int HD, int D> constexpr int stash_n() { return (D == 8 && HD >= 32) ? 4 : (D == 4 ? 2 : 0); }
 // GAT_ROWGROUP=0: one wave per row (chunked kernels) instead of one lane group per row (A/B)
 static bool row_groups() {
-    static const bool v = [] { const char* e = getenv("GAT_ROWGROUP"); return !(e && e[0] == '0'); }();
+    static const bool v = [] { const char* e = choice_env("GAT_ROWGROUP"); return !(e && e[0] == '0'); }();
     return v;
 }
 // GAT_PACKED=0 keeps the one-channel-per-lane kernels on the training path too (A/B)
 static bool packed_layout() {
-    static const bool v = [] { const char* e = getenv("GAT_PACKED"); return !(e && e[0] == '0'); }();
+    static const bool v = [] { const char* e = choice_env("GAT_PACKED"); return !(e && e[0] == '0'); }();
     return v;
 }
 // channels per lane of the packed kernels where the shape allows 4 (H*D >= 32, D % 4 == 0): GAT_CPL=2|4 (A/B)
 static int lane_channels() {
-    static const int v = [] { const char* e = getenv("GAT_CPL"); return (e && e[0] == '2') ? 2 : 4; }();
+    static const int v = [] { const char* e = choice_env("GAT_CPL"); return (e && e[0] == '2') ? 2 : 4; }();
     return v;
 }
 
@@ -1811,7 +1814,7 @@ int run_fwd(const EdgeFwdArgs& a, hipStream_t s) {
             if (packed_layout()) {                   // two or four channels per lane (see edge_fwd2_kernel)
                 // one wave per block: a 4-wave block lives as long as its longest item (a 256-edge segment next to
                 // 10-edge rows) and pins the other three wave slots meanwhile — 5.51 -> 5.02 ms per step
-                static const int wpb = [] { const char* e = getenv("GAT_FWD_WAVES"); const int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
+                static const int wpb = [] { const char* e = choice_env("GAT_FWD_WAVES"); const int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
                 const dim3 grid((unsigned)((a.n_items + wpb - 1) / wpb)), block(64 * wpb);
                 if constexpr (stash_n<HD, D>() != 0) {        // group-per-row kernel (GAT_ROWGROUP=0: the chunked one, A/B)
                     if (row_groups()) {
@@ -1868,7 +1871,7 @@ static int resident_blocks(const void* fn) {
 static bool packed_backward() { return packed_layout(); }
 // GAT_GROUP_MSG=0: message-row layers on the wave-per-row kernel (edge_bwd2_kernel) instead of the group-per-row one (A/B)
 static bool group_msg() {
-    static const bool v = [] { const char* e = getenv("GAT_GROUP_MSG"); return !(e && e[0] == '0'); }();
+    static const bool v = [] { const char* e = choice_env("GAT_GROUP_MSG"); return !(e && e[0] == '0'); }();
     return v;
 }
 struct BwdSel { bool store, taps, bf16, stash; };
@@ -1904,10 +1907,12 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
     if (a.items == nullptr) return fail(GAT_E_INVALID, "edge_backward: work-item list missing");
     const dim3 grid((unsigned)a.ga_blocks), block(256);
     const bool store = a.pos != nullptr && a.msg != nullptr, taps = a.ge != nullptr;
-    if constexpr (HD == 64 && D == 8) {          // timing experiments (GAT_DBG=1: no message store, 2: sequential slots)
+#ifdef GAT_EXPERIMENTS
+    if constexpr (HD == 64 && D == 8) {          // timing experiments (GAT_DBG=1: no message store, 2: sequential slots) — WRONG RESULTS
         if (store && !taps && a.stash == nullptr && a.dbg == 1) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 1>), grid, block, 0, s, a); return 0; }
         if (store && !taps && a.stash == nullptr && a.dbg == 2) { hipLaunchKernelGGL((edge_bwd_kernel<HD, D, true, false, 2>), grid, block, 0, s, a); return 0; }
     }
+#endif
     bool launched = false;
     if constexpr (stash_n<HD, D>() != 0) {
         if (a.stash != nullptr && !taps && a.bf16) {                // bf16 storage: always the group-per-row kernel
@@ -1918,6 +1923,7 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
         if (a.stash != nullptr && !taps && !a.bf16) {
             if (a.gfull == nullptr || a.pos == nullptr) return fail(GAT_E_INVALID, "edge_backward: stash path needs gfull and pos");
             bool dbg_done = false;
+#ifdef GAT_EXPERIMENTS                               // GAT_DBG exists in the experiment library only (make experiments): most values give WRONG results
             if constexpr (HD == 64 && D == 8) {      // timing experiments (GAT_DBG=1: no record store, 2: records in CSR order)
                 if (a.dbg == 9 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 9>), grid, block, 0, s, a); dbg_done = true; }   // double walk
                 else if (a.dbg == 10 && row_groups()) { hipLaunchKernelGGL((edge_bwd3_kernel<64, 8, 4, 10>), grid, block, 0, s, a); dbg_done = true; }   // scatter folded into 64 MiB
@@ -1940,6 +1946,7 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
                 else if (a.dbg == 1) { hipLaunchKernelGGL((edge_bwd2s_kernel<64, 8, 4, 1>), grid, block, 0, s, a); dbg_done = true; }
                 else if (a.dbg == 2) { hipLaunchKernelGGL((edge_bwd2s_kernel<64, 8, 4, 2>), grid, block, 0, s, a); dbg_done = true; }
             }
+#endif
             if (!dbg_done) {
                 if (row_groups()) hipLaunchKernelGGL((edge_bwd3_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
                 else hipLaunchKernelGGL((edge_bwd2s_kernel<HD, D, stash_n<HD, D>()>), grid, block, 0, s, a);
@@ -2048,9 +2055,11 @@ int edge_backward_blocks(int64_t n_items, int32_t H, int32_t D_, bool store, boo
         return 2048;                                  // generic path: one wave per block
     };
     int c = cap();
-    // GAT_DBG=4 (experiment): 512-thread blocks of edge_bwd4_kernel — two resident per CU instead of four
+    // experiment library, GAT_DBG=4: 512-thread blocks of edge_bwd4_kernel — two resident per CU instead of four
+#ifdef GAT_EXPERIMENTS
     static const int dbg = [] { const char* e = getenv("GAT_DBG"); return e ? atoi(e) : 0; }();
     if (dbg == 4 && HD == 64 && D == 8 && stash && !bf16 && !taps) c = c / 2;
+#endif
     return (int)(want < c ? want : c);
 }
 

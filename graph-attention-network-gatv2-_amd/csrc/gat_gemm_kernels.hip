@@ -646,9 +646,9 @@ __global__ __launch_bounds__(256) void project_reduce_kernel(const float* __rest
 }
 // rows few enough that the streaming kernel would leave most CUs idle, K long enough to be worth splitting
 static bool project_wants_splitk(int64_t M, int32_t N, int32_t K) {
-    static const bool off = [] { const char* e = getenv("GAT_PROJECT_SPLITK"); return e && e[0] == '0'; }();     // A/B
-    static const int x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return e ? atoi(e) : -1; }();
-    static const int kmax_env = [] { const char* e = getenv("GAT_X3_KMAX"); return e ? atoi(e) : 128; }();            // A/B: 512 = row-streaming kernel up to K = 512
+    static const bool off = [] { const char* e = choice_env("GAT_PROJECT_SPLITK"); return e && e[0] == '0'; }();     // A/B
+    static const int x3 = [] { const char* e = choice_env("GAT_GEMM_X3"); return e ? atoi(e) : -1; }();
+    static const int kmax_env = [] { const char* e = choice_env("GAT_X3_KMAX"); return e ? atoi(e) : 128; }();            // A/B: 512 = row-streaming kernel up to K = 512
     const int kmax = x3 != 0 ? kmax_env : 128;       // up to here the row-streaming kernel keeps all of K in LDS (run_rowgemm)
     return !off && K > kmax && ((M + 127) / 128) * ((N + 127) / 128) < 256;
 }
@@ -657,7 +657,7 @@ template <class AS, class BS, class EP>
 int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, int32_t K, bool vec4, hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     int NT = N > 64 ? 4 : (N > 32 ? 2 : 1);
-    static const int x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return e ? atoi(e) : -1; }();  // A/B: 0 = fp32 MFMA; 4 / 8 = force waves per block
+    static const int x3 = [] { const char* e = choice_env("GAT_GEMM_X3"); return e ? atoi(e) : -1; }();  // A/B: 0 = fp32 MFMA; 4 / 8 = force waves per block
     // B (all of K x the block's columns, three piece planes) must fit in LDS: K <= 128 with 128 columns per block.  Narrower
     // column slices would take K up to 512 (the Pubmed shape's 500: four slices, A re-read per slice from L2), but measured
     // there it only ties the split-K kernel (0.245-0.259 vs 0.252 ms per step) and one 500-long accumulation chain is less
@@ -694,7 +694,7 @@ int run_rowgemm(const AS& as, const BS& bs, const EP& ep, int64_t M, int32_t N, 
     const size_t lds = (size_t)kc_lds * NW * sizeof(float);
     const int64_t ntiles = (M + 127) / 128;
     if constexpr (!EP::kTwoPhase) {
-        static const bool pipe = [] { const char* e = getenv("GAT_GEMM_PIPE"); return !(e && e[0] == '0'); }();   // A/B
+        static const bool pipe = [] { const char* e = choice_env("GAT_GEMM_PIPE"); return !(e && e[0] == '0'); }();   // A/B
         // only up to 64 output columns per block: with 128 (64 accumulator + 148 other registers = 2 waves per SIMD
         // either way) the pipelined form measured 1.31 vs 1.22 ms per step for the projections; grad_x 0.56 -> 0.48
         if (vec4 && K <= kKC && pipe && NT <= 2) {
@@ -1042,7 +1042,7 @@ inline int grad_w_bm(int32_t M) { return (M % 128 == 0 || M % 128 > 64) ? 128 : 
 inline int grad_w_bn(int32_t M, int32_t F) { return (grad_w_bm(M) == 128 && F <= 64) ? 64 : 128; }   // 64 only in the 2x2-wave shape
 
 static bool grad_w_x3() {
-    static const bool on = [] { const char* e = getenv("GAT_GRADW_X3"); return !(e && e[0] == '0'); }();     // A/B: 0 = fp32 MFMA
+    static const bool on = [] { const char* e = choice_env("GAT_GRADW_X3"); return !(e && e[0] == '0'); }();     // A/B: 0 = fp32 MFMA
     return on;
 }
 int64_t grad_w_kchunk(int64_t n_rows, int32_t F, int32_t M) {
@@ -1082,10 +1082,10 @@ int launch_project(const float* X, const float* W, float* PL_rows, float* PR, in
     if (scratch != nullptr && n_rows > 0 && project_wants_splitk(n_rows, N, F) && scratch_floats >= (int64_t)((F + 127) / 128) * n_rows * N) {
         const int ksplit = (F + 127) / 128;
         const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)ksplit);
-        static const bool x3 = [] { const char* e = getenv("GAT_GEMM_X3"); return !(e && e[0] == '0'); }();       // A/B: 0 = fp32 MFMA
+        static const bool x3 = [] { const char* e = choice_env("GAT_GEMM_X3"); return !(e && e[0] == '0'); }();       // A/B: 0 = fp32 MFMA
         if (x3) {
             // 64-column blocks (48 KiB of LDS: three per CU) unless GAT_SPLITK_NT=4: Pubmed-shape 0.311 -> 0.302 ms per step
-            static const int nt = [] { const char* e = getenv("GAT_SPLITK_NT"); return e && atoi(e) == 4 ? 4 : 2; }();
+            static const int nt = [] { const char* e = choice_env("GAT_SPLITK_NT"); return e && atoi(e) == 4 ? 4 : 2; }();
             const size_t lds = (size_t)3 * 8 * 2 * (nt * 32) * sizeof(uint4);
             if (nt == 4) { allow_big_lds((const void*)project_splitk_x3_kernel<true, 4>); allow_big_lds((const void*)project_splitk_x3_kernel<false, 4>); }
             const dim3 grid3((unsigned)((n_rows + 127) / 128), (unsigned)((N + nt * 32 - 1) / (nt * 32)), (unsigned)ksplit);

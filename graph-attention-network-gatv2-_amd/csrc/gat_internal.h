@@ -15,6 +15,9 @@ constexpr int kWave = 64;
 
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+// getenv for CHOICE switches (same results, other kernel / launch shape): records what was set for gat_switches().  Timing-only and
+// wrong-result experiments (GAT_DBG) are not choice switches: they exist only in a -DGAT_EXPERIMENTS build (make experiments).
+const char* choice_env(const char* name);
 
 #define GAT_HIP(expr)                                                                     \
     do {                                                                                  \
@@ -174,6 +177,9 @@ int launch_gpl_sum(const int32_t* src_ptr, const float* msg, float* gPL, int64_t
                    int32_t n_heavy, float* part, hipStream_t s, const SlotRuns* runs = nullptr);
 // slots of padding behind the record buffer and the destination list: the pull pass reads whole 16-slot chunks (and one chunk
 // of destinations ahead) without clamping its indices
+// REQUIREMENT on callers of launch_gpl_pull: pass the allocated slot count as slot_capacity; below n_slots + kPullPad the clamped
+// first form is used.  The padding's CONTENT is not relied on (slots beyond a list are zeroed after their load), only its presence;
+// the gathered tables are addressed with 32-bit byte offsets (n_table * H*D * 4 < 4 GiB: edge_fast_path; node records: n_rows < 2^26).
 constexpr int64_t kPullPad = 32;
 // cdst[pos[e]] = destination row of CSR edge e (the source-major twin of a1's dst array; built once per graph)
 int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int64_t n_rows, int64_t n_edges, hipStream_t s);
@@ -182,7 +188,8 @@ int build_csc_dst(const int32_t* row_ptr, const int32_t* pos, int32_t* cdst, int
 int launch_gpl_pull(const int32_t* src_ptr, const uint32_t* stash, const int32_t* cdst, const float* gfull, bool g_bf16,
                     const float* gh, const uint8_t* hbits, int32_t gh_stride, int32_t hb_stride, const float* a,
                     float slope, float* gPL, int64_t n_table, int64_t n_slots, int32_t H, int32_t D, const int4* chunks,
-                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, const SlotRuns* runs, hipStream_t s);
+                    int32_t n_chunks, const int4* heavy, int32_t n_heavy, float* part, const int4* items, int64_t n_items, const SlotRuns* runs,
+                    int64_t slot_capacity /* slots allocated in stash AND cdst: n_slots + kPullPad enables the unclamped forms */, hipStream_t s);
 
 int launch_csr_to_coo(const int32_t* row_ptr, const int32_t* col_idx, int32_t* src, int32_t* dst,
                       int64_t n_rows, int64_t n_edges, int64_t table_row0, hipStream_t s);

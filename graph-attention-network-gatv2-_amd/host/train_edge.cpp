@@ -381,6 +381,17 @@ int run(const Options& o, const RankEnv& env) {
             check(gat_comm_init_host(ctx, env.world, env.rank, env.shm_name.c_str(), bytes), "gat_comm_init_host");
         }
     }
+    // the 4 GiB cliff of gatv2_abi.h "Limits" is never silent: ask every layer which kernels it runs on
+    if (env.rank == 0) {
+        std::string slow;
+        for (int l = 0; l < L; ++l) {
+            int32_t path = GAT_PATH_FAST;
+            if (gat_layer_path(ctx, l, &path) == 0 && path == GAT_PATH_GENERIC_SIZE) slow += (slow.empty() ? "" : ", ") + std::to_string(l);
+        }
+        if (!slow.empty())
+            fprintf(stderr, "Warning: layer(s) %s: the gathered source table is >= 4 GiB; these layers run on the generic float-atomic kernels "
+                            "(same results, several times slower) — use --ranks to shard by destination range\n", slow.c_str());
+    }
     // optional splits: loss / accuracy / gradient over the training nodes, an extra validation line per epoch
     std::vector<uint8_t> train_m, val_m;
     int64_t n_train = N;

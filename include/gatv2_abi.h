@@ -65,6 +65,11 @@ enum { GAT_DTYPE_F32 = 0, GAT_DTYPE_BF16 = 1 };
 const char* gat_last_error(void);
 int gat_abi_version(void);
 int gat_device_count(int* count);
+/* The environment switches this process has read and found set, as "NAME=VALUE NAME=VALUE" (empty string: none).  They select among
+ * kernels / launch shapes that compute the same results (A/B measurements and the test matrices use them) — never a
+ * different result: the timing-only experiment variants (GAT_DBG) exist only in the experiment library (`make experiments`,
+ * libgatv2_hip_exp.so, whose text starts with "[experiment library]").  buf: at least a few hundred bytes. */
+int gat_switches(char* buf, int64_t cap);
 
 /* ---- lifecycle (replaces the inline cudaMalloc plan, E:1151-1357) ------------------------- */
 int gat_create(const gat_config* cfg, gat_ctx** out);
@@ -87,7 +92,9 @@ int gat_set_graph(gat_ctx* ctx, const int32_t* row_ptr, const int32_t* col_idx, 
                   int64_t n_edges, int64_t n_table, int64_t table_row0);
 /* Which edge kernels layer `layer` runs on (known once the graph is set).  The size cliff above is never silent: the
  * gat_set_* call that completes the context (graph + features + labels) still returns 0, but leaves a text starting with
- * "warning:" in gat_last_error() when a layer is GAT_PATH_GENERIC_SIZE. */
+ * "warning:" in gat_last_error() when a layer is GAT_PATH_GENERIC_SIZE (one text naming every affected layer; any later
+ * failing call replaces it).  gat_last_error() is a per-thread last-message slot, so the durable way to find out is this query:
+ * call it for every layer after the context is complete (train_edge does, and prints the warning once to stderr). */
 enum {
     GAT_PATH_GENERIC_SHAPE = 0,   /* (H, D) outside the wave-per-row templates (H*D not in {8,16,32,64} or D not a power of two) */
     GAT_PATH_FAST = 1,            /* wave-per-row / group-per-row kernels, no atomics */
@@ -268,7 +275,11 @@ int gat_op_layer_backward(const int32_t* d_row_ptr, const int32_t* d_col_idx, co
  *      A maintainer can swap a single launch of the reference's main() for the matching call and keep everything else
  *      (INTEGRATION.md §2b).  Scratch (projected features, message tables) is allocated per call; calls synchronise their
  *      stream.  Scatters use float atomics like the reference's own kernels (sums over edges order-dependent at fp32
- *      round-off).  csrc/gat_ops.hip. -------------------------------------------------------------------------------- */
+ *      round-off).  csrc/gat_ops.hip.
+ *      THESE ARE PARITY SEAMS, NOT THE FAST PATH: every call hipMalloc's and frees its scratch, re-projects X.W on the matrix cores,
+ *      synchronises the stream, and scatters with global float atomics (~1.3 TB/s on this chip).  A maintainer who wants the speed
+ *      swaps the epoch loop for gat_step / the phase API on a context (which owns its buffers and runs without atomics or
+ *      per-call allocation), not kernel by kernel. ---------------------------------------------------------------------- */
 /* a2  gatv2_edge_score_kernel E:279-324, launch E:1386: attn_score[h][e] (overwritten) */
 int gat_op_edge_score(const float* d_input_features, const int32_t* d_col_idx, const int32_t* d_dst, const float* d_w,
                       const float* d_a, float* d_attn_score, int64_t n, int32_t in_dim, int32_t out_dim, int32_t h,

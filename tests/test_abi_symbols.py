@@ -71,3 +71,15 @@ def test_algorithmic_bytes_match_the_survey_worked_values(pkg):
     bf, _ = A.algorithmic_bytes_shape((4, 4), (8, 8), 128, 47, 10_000_000, 250_000_000, dtype="bf16")
     idx = 2 * 2 * (4 * (10_000_000 + 1) + 4 * 250_000_000) + 2 * 4 * 10_000_000 * (8 + 2 * 47 + 2)
     assert abs((f32 - idx) / 2 + idx - bf) < 1.0
+
+
+def test_release_library_does_not_contain_the_experiment_switch():
+    """The timing-only / wrong-result variants (GAT_DBG) are compiled into libgatv2_hip_exp.so only (-DGAT_EXPERIMENTS): the
+    release library must not even contain the name, so no environment variable can make it produce other results."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rel = os.path.join(root, "graph-attention-network-gatv2-_amd", "libgatv2_hip.so")
+    assert b"GAT_DBG" not in open(rel, "rb").read()
+    exp = os.path.join(root, "graph-attention-network-gatv2-_amd", "libgatv2_hip_exp.so")
+    if os.path.exists(exp):
+        assert b"GAT_DBG" in open(exp, "rb").read()

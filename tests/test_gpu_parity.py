@@ -325,6 +325,45 @@ def test_step_graph_replay_is_bitwise_the_eager_step(pkg, orc):
     assert abs(outs[1][0][0] - ref.loss_sum_f64) / 300 < TOL
 
 
+def test_release_library_ignores_gat_dbg(tmp_path):
+    """GAT_DBG selects timing-only variants that produce WRONG results (1: no record stores).  They are compiled into the experiment
+    library only; with the release library a stray GAT_DBG in the environment must leave every gradient bit unchanged, and
+    gat_switches() must not list it."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import __graft_entry__ as entry
+        from conftest import small_graph
+        pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
+        rng = np.random.default_rng(5)
+        rp, ci = small_graph(rng, 400, 6000, hub=(9, 700), empty=(0, 3))
+        x = rng.standard_normal((400, 12)).astype(np.float32)
+        lab = rng.integers(0, 4, 400).astype(np.int32); lab[0] = 3
+        cfg = orc.Config([8, 8], [8, 8], 12, 4)
+        W, a, Wo = orc.xavier_params(cfg, 6)
+        ctx = pkg.GatContext([8, 8], [8, 8], 12, 4)
+        ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
+        for g, arr in enumerate((W, a, Wo)): ctx.params_set(g, arr)
+        ctx.zero_grad(); loss, correct = ctx.step()
+        np.savez(sys.argv[1], g=np.concatenate([[loss, correct]] + [ctx.grads_get(g).ravel() for g in range(3)]))
+        ctx.close()
+        print("SWITCHES<" + A.switches() + ">")
+    """)
+    outs = []
+    for tag, env in (("plain", {}), ("dbg1", {"GAT_DBG": "1"}), ("dbg3", {"GAT_DBG": "3", "GAT_PULL_LAST": "1"})):
+        f = str(tmp_path / (tag + ".npz"))
+        env_all = {k: v for k, v in os.environ.items() if k not in ("GAT_DBG", "GATV2_LIB")}
+        out = subprocess.run([sys.executable, "-c", code, f], env=dict(env_all, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "SWITCHES<" in out.stdout, out.stderr[-2000:]
+        assert "GAT_DBG" not in out.stdout and "experiment" not in out.stdout
+        if tag == "dbg3":
+            assert "GAT_PULL_LAST=1" in out.stdout                      # choice switches ARE reported
+        outs.append(np.load(f)["g"])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_grad_w_overlap_is_bitwise_the_serial_order(tmp_path):
     """gat_step / gat_backward run every hidden layer's grad_w on a side stream (second gPL / gPR pair for the odd layers, fork /
     join events — a fork / join in the captured graph): same kernels on the same operands, so the gradients must be BITWISE those
@@ -419,8 +458,12 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
                                  # split rows and the wave-per-row backward
                                  {"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"},
                                  {"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "0", "GAT_GPL_HEAVY": "16", "GAT_ROWGROUP": "0"},
-                                 # the wave-specialised record-store experiment kernels (measured, not the default)
-                                 {"GAT_DBG": "4"}, {"GAT_DBG": "5", "GAT_PULL_LAST": "1"}, {"GAT_DBG": "6"},
+                                 # the wave-specialised record-store experiment kernels (measured, not the default) live in the
+                                 # experiment library only: loaded through GATV2_LIB
+                                 {"GAT_DBG": "4", "GATV2_LIB": "exp"}, {"GAT_DBG": "5", "GAT_PULL_LAST": "1", "GATV2_LIB": "exp"}, {"GAT_DBG": "6", "GATV2_LIB": "exp"},
+                                 # ... and the release library must not even know the name: GAT_DBG=1 (no record stores: wrong gradients in
+                                 # the experiment library) changes nothing here
+                                 {"GAT_DBG": "1"}, {"GAT_OVERLAP": "1"},
                                  # message rows from the wave-per-row backward (config 5's round-2 kernel; the group-per-row one is the default
                                  # of the GAT_BWD_STASH=0 settings above)
                                  {"GAT_BWD_STASH": "0", "GAT_GROUP_MSG": "0"},

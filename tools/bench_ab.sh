@@ -4,8 +4,11 @@
 out=$1; wl=$2; dt=$3; shift 3
 mkdir -p "$out"
 i=0
+root=$(cd "$(dirname "$0")/.." && pwd)
 for e in "$@"; do
   echo "$i: $e" >> "$out/ab_index.txt"
+  # GAT_DBG (timing-only / wrong-result experiments) exists only in the experiment library
+  case "$e" in *GAT_DBG*) e="$e GATV2_LIB=$root/graph-attention-network-gatv2-_amd/libgatv2_hip_exp.so";; esac
   env $e timeout -k 10 300 python bench.py --workload "$wl" --dtype "$dt" --no-cpu-baseline --steps ${STEPS:-10} --warmup 3 > "$out/ab_$i.json" 2> "$out/ab_$i.err" || { echo "run $i failed"; tail -5 "$out/ab_$i.err"; exit 1; }
   python - "$out/ab_$i.json" "$e" <<'PY'
 import json,sys
