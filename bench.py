@@ -344,6 +344,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         step_traffic = measured_traffic(args, world, None)
+        req_bytes_step = A.request_bytes_shape(heads, outdims, f, c, n, e, dtype=args.dtype)[0] if world == 1 and args.scale == 1.0 else None
         timed = [k for k in stats if stats[k][0] > 0 and k not in ("misc", "exchange")]
         if timed:
             dom = max(timed, key=lambda k: stats[k][1])
@@ -389,6 +390,11 @@ def main():
                               # ratio to the algorithmic bytes: > 1 = traffic the algorithm does not need
                               "traffic": step_traffic, "traffic_source": measured_traffic_src(args, world, None)[1],
                               "traffic_over_algorithmic": (step_traffic / bytes_step_all) if step_traffic else None,
+                              # the same model with every per-edge gathered / scattered row rounded up to whole 128-byte fabric requests
+                              # (gat_request_bytes_shape): what the memory system can serve — differs from the figure above for bf16 rows at
+                              # H*D < 64 (config 5: 64-byte rows cost a line each); single GPU only
+                              "request_granular_GB_per_step": (req_bytes_step / 1e9) if req_bytes_step else None,
+                              "frac_request_granular": (req_bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if req_bytes_step else None,
                               "training_path_GB_per_step": (tp_bytes_step / 1e9) if tp_bytes_step else None,
                               "frac_training_path": (tp_bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS) if tp_bytes_step else None,
                               "note": pmc_note},

@@ -184,6 +184,7 @@ def _declare(lib: C.CDLL) -> None:
         "gat_kernel_stats_reset": [vp],
         "gat_algorithmic_bytes": [vp, P(C.c_double), P(C.c_double)],
         "gat_algorithmic_bytes_shape": [P(_Config), i64, i64, i64, i32, P(C.c_double), P(C.c_double)],
+        "gat_request_bytes_shape": [P(_Config), i64, i64, i64, i32, P(C.c_double), P(C.c_double)],
         "gat_synth_sources_device": [vp, vp, vp, i64, i64, C.c_uint64, vp, vp],
         "gat_synth_features_device": [C.c_uint64, i64, i64, i32, i32, vp, vp],
         "gat_synth_labels_device": [C.c_uint64, i64, i64, i32, vp, vp],
@@ -525,6 +526,24 @@ def algorithmic_bytes_shape(heads: Sequence[int], outdims: Sequence[int], in_dim
     per = (C.c_double * K_COUNT)()
     _chk(lib.gat_algorithmic_bytes_shape(C.byref(cfg), n_rows, n_edges, n_rows if n_table is None else n_table,
                                          int(replicated_input), C.byref(tot), per))
+    return tot.value, {lib.gat_kernel_name(k).decode(): per[k] for k in range(K_COUNT)}
+
+
+def request_bytes_shape(heads: Sequence[int], outdims: Sequence[int], in_dim: int, num_classes: int, n_rows: int,
+                        n_edges: int, *, dtype: str = "f32", n_table: Optional[int] = None, replicated_input: bool = False):
+    """The same byte model with every per-edge gathered / scattered row rounded up to whole 128-byte fabric requests
+    (gat_request_bytes_shape): the roofline the memory system can serve.  -> (bytes_step, {kernel class: bytes})"""
+    lib = load_library()
+    L = len(heads)
+    h = (C.c_int32 * L)(*heads); d = (C.c_int32 * L)(*outdims)
+    cfg = _Config()
+    cfg.num_layers, cfg.heads, cfg.outdims = L, h, d
+    cfg.in_dim, cfg.num_classes = int(in_dim), int(num_classes)
+    cfg.storage_dtype = 1 if dtype == "bf16" else 0
+    tot = C.c_double()
+    per = (C.c_double * K_COUNT)()
+    _chk(lib.gat_request_bytes_shape(C.byref(cfg), n_rows, n_edges, n_rows if n_table is None else n_table,
+                                     int(replicated_input), C.byref(tot), per))
     return tot.value, {lib.gat_kernel_name(k).decode(): per[k] for k in range(K_COUNT)}
 
 

@@ -178,6 +178,7 @@ struct gat_ctx {
     int4* items = nullptr; int4* slot_info = nullptr;
     float* part_acc = nullptr; float* part_mz = nullptr;
     float* ga_partial = nullptr; int32_t ga_blocks = 0;
+    uint32_t* tile_counters = nullptr; int64_t n_tile_counters = 0;      // arrival counters of the latency-sized split-K projection (zero between launches)
     float* gw_scratch = nullptr; int64_t gw_scratch_floats = 0; std::vector<int64_t> gw_off;       // [L] first float of each layer's grad_w slab region
     float* hb_partial = nullptr;
     double* loss_partial = nullptr; int32_t* correct_partial = nullptr;
@@ -409,6 +410,19 @@ static int ensure_buffers(gat_ctx* c) {
     }
     GAT_TRY(dalloc(c, &c->gw_scratch, gw));
     c->gw_scratch_floats = gw;
+    {   // one arrival counter per 64 x 64 output tile of a split-K projection launch (only launches with a slab scratch use them)
+        int64_t nc = 1;
+        for (int l = 0; l < L; ++l) {
+            const Layer& y = c->layers[l];
+            if (l == 0 && c->Xtab) {
+                if (project_scratch_floats(T, y.F, y.HD, kPartLeft) > 0) nc = std::max(nc, project_tile_counters(T, y.HD, kPartLeft));
+                if (project_scratch_floats(N, y.F, y.HD, kPartRight) > 0) nc = std::max(nc, project_tile_counters(N, y.HD, kPartRight));
+            } else if (project_scratch_floats(N, y.F, y.HD, kPartBoth) > 0) nc = std::max(nc, project_tile_counters(N, y.HD, kPartBoth));
+        }
+        GAT_TRY(dalloc(c, &c->tile_counters, nc));
+        GAT_HIP(hipMemsetAsync(c->tile_counters, 0, (size_t)nc * sizeof(uint32_t), c->stream));
+        c->n_tile_counters = nc;
+    }
     const int C = c->cfg.num_classes, DL = c->layers[L - 1].D;
     GAT_TRY(dalloc(c, &c->hb_partial, (int64_t)head_bwd_blocks(N, C, DL) * C * DL));
     GAT_TRY(dalloc(c, &c->loss_partial, head_blocks(N)));
@@ -788,11 +802,11 @@ int gat_layer_project(gat_ctx* c, int32_t l) {
     Layer& y = c->layers[l];
     Scope t(c, GAT_K_PROJECT);
     if (l == 0 && c->Xtab) {      // replicated input: whole PL table from the table rows, PR from the shard's rows
-        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream));
-        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream);
+        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream, c->tile_counters, c->n_tile_counters));
+        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream, c->tile_counters, c->n_tile_counters);
     }
     float* own_rows = reinterpret_cast<float*>(reinterpret_cast<char*>(y.PL) + c->table_row0 * y.HD * st_bytes(c));
-    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream);
+    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream, c->tile_counters, c->n_tile_counters);
 }
 
 static EdgeFwdArgs plan_forward_edges(gat_ctx* c, int32_t l);
@@ -1723,6 +1737,26 @@ int gat_algorithmic_bytes_shape(const gat_config* cfg, int64_t n_rows, int64_t n
     }
     const double head = 2.0 * 4.0 * N * ((double)cfg->outdims[L - 1] + 2.0 * cfg->num_classes + 2.0);
     k[GAT_K_HEAD_FWD] = head / 2; k[GAT_K_HEAD_BWD] = head / 2;
+    double tot = 0;
+    for (int i = 0; i < GAT_K_COUNT; ++i) { tot += k[i]; if (per_kernel) per_kernel[i] = k[i]; }
+    if (bytes_step) *bytes_step = tot;
+    return 0;
+}
+// The same model with every RANDOM row access priced at what the memory system can serve: the fabric moves 128-byte requests
+// (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ in every PMC pass of this build), so a gathered or scattered row of b*H*D bytes costs
+// ceil(b*H*D / 128) * 128.  Identical to SURVEY 8d's figure wherever a row is a multiple of 128 B (fp32 at H*D = 64: 256 B);
+// for bf16 rows at H*D = 32 (BASELINE config 5: 64-byte rows) the three per-edge row terms double.  Sequential streams
+// (indices, attention coefficients, node-major rows) are unchanged.
+int gat_request_bytes_shape(const gat_config* cfg, int64_t n_rows, int64_t n_edges, int64_t n_table,
+                            int32_t replicated_input, double* bytes_step, double* per_kernel) {
+    double k[GAT_K_COUNT] = {0};
+    GAT_TRY(gat_algorithmic_bytes_shape(cfg, n_rows, n_edges, n_table, replicated_input, nullptr, k));
+    const double E = (double)n_edges, b = cfg->storage_dtype == GAT_DTYPE_BF16 ? 2.0 : 4.0;
+    for (int l = 0; l < cfg->num_layers; ++l) {
+        const double row = b * (double)cfg->heads[l] * cfg->outdims[l];
+        const double extra = E * (std::ceil(row / 128.0) * 128.0 - row);
+        k[GAT_K_EDGE_FWD] += extra; k[GAT_K_EDGE_BWD] += extra; k[GAT_K_GPL_SUM] += extra;      // PL[src] twice, the gPL scatter once
+    }
     double tot = 0;
     for (int i = 0; i < GAT_K_COUNT; ++i) { tot += k[i]; if (per_kernel) per_kernel[i] = k[i]; }
     if (bytes_step) *bytes_step = tot;

@@ -1955,6 +1955,14 @@ int run_bwd(const EdgeBwdArgs& a, hipStream_t s) {
         }
     }
     if constexpr (stash_n<HD, D>() != 0) {
+#ifdef GAT_EXPERIMENTS       // GAT_DBG=1 on a message-row layer (BASELINE config 5): the walk without its message-row stores — WRONG RESULTS, timing / PMC
+        if constexpr (HD == 32 && D == 8) {           // attribution only (DESIGN §4 "Round 4": how much of the backward's reads is fill for its 64-byte row writes)
+            if (!launched && store && !taps && packed_backward() && row_groups() && group_msg() && a.bf16 && a.dbg == 1) {
+                hipLaunchKernelGGL((edge_bwd3_kernel<HD, D, stash_n<HD, D>(), 1, true, true>), grid, block, 0, s, a);
+                launched = true;
+            }
+        }
+#endif
         if (!launched && store && !taps && packed_backward() && row_groups() && group_msg()) {
             if (a.bf16) hipLaunchKernelGGL((edge_bwd3_kernel<HD, D, stash_n<HD, D>(), 0, true, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((edge_bwd3_kernel<HD, D, stash_n<HD, D>(), 0, false, true>), grid, block, 0, s, a);

@@ -376,6 +376,12 @@ int gat_algorithmic_bytes(gat_ctx* ctx, double* bytes_step, double* bytes_per_ke
  * outdims, in_dim, num_classes and storage_dtype are read. */
 int gat_algorithmic_bytes_shape(const gat_config* cfg, int64_t n_rows, int64_t n_edges, int64_t n_table,
                                 int32_t replicated_input, double* bytes_step, double* bytes_per_kernel);
+/* The same model at the granularity the memory fabric serves: every per-edge gathered / scattered row (PL[src] in both edge
+ * passes, the gPL scatter) rounded up to whole 128-byte requests.  Equal to the figure above when a row is a multiple of 128 B
+ * (fp32, H*D = 64); larger for bf16 rows at H*D < 64 (BASELINE config 5: 64-byte rows cost a line each) — the roofline such a
+ * shape can actually be served at.  bench.py reports it as `frac_request_granular`. */
+int gat_request_bytes_shape(const gat_config* cfg, int64_t n_rows, int64_t n_edges, int64_t n_table,
+                            int32_t replicated_input, double* bytes_step, double* bytes_per_kernel);
 
 #ifdef __cplusplus
 }

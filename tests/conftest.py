@@ -60,3 +60,22 @@ def _parity_test_name(request):
 def pytest_sessionfinish(session, exitstatus):
     import parity
     parity.flush()
+
+
+def run_snippets_parallel(jobs, workers=5, timeout=900):
+    """jobs: {key: (python code, env overrides)} -> {key: CompletedProcess}.  The switch / fuzz matrices run one subprocess per
+    setting (the switches are read once per process); `workers` of them at a time share the GPU (the box allows 6 processes on its
+    card) — the matrices are bound by the CPU oracle and the fp64 reference, not by the GPU."""
+    import concurrent.futures as cf
+    import subprocess
+    import sys as _sys
+
+    def one(item):
+        key, (code, env) = item
+        try:
+            return key, subprocess.run([_sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired as e:
+            return key, subprocess.CompletedProcess(e.cmd, 124, stdout=(e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or ""),
+                                                    stderr="TIMEOUT after %d s" % timeout)
+    with cf.ThreadPoolExecutor(max_workers=workers) as ex:
+        return dict(ex.map(one, list(jobs.items())))

@@ -53,15 +53,19 @@ def flush():
     try:
         os.makedirs(out, exist_ok=True)
         path = os.path.join(out, "parity_errors.json")
-        old = {}
-        if os.path.exists(path):
-            try:
-                old = json.load(open(path))
-            except Exception:      # noqa: BLE001 - a truncated file from a killed run is simply replaced
-                old = {}
-        old.update(_LOG)
-        with open(path, "w") as f:
-            json.dump(old, f, indent=1, sort_keys=True)
+        import fcntl
+        with open(path + ".lock", "w") as lk:          # the switch / fuzz matrices run several test processes at once
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            old = {}
+            if os.path.exists(path):
+                try:
+                    old = json.load(open(path))
+                except Exception:      # noqa: BLE001 - a truncated file from a killed run is simply replaced
+                    old = {}
+            old.update(_LOG)
+            with open(path + ".tmp", "w") as f:
+                json.dump(old, f, indent=1, sort_keys=True)
+            os.replace(path + ".tmp", path)
     except OSError:
         pass
 

@@ -71,6 +71,15 @@ def test_algorithmic_bytes_match_the_survey_worked_values(pkg):
     bf, _ = A.algorithmic_bytes_shape((4, 4), (8, 8), 128, 47, 10_000_000, 250_000_000, dtype="bf16")
     idx = 2 * 2 * (4 * (10_000_000 + 1) + 4 * 250_000_000) + 2 * 4 * 10_000_000 * (8 + 2 * 47 + 2)
     assert abs((f32 - idx) / 2 + idx - bf) < 1.0
+    # request-granular model (gat_request_bytes_shape): a row that is a multiple of 128 B changes nothing; config 5's 64-byte bf16
+    # rows cost a 128-byte request each in the three per-edge row terms of both layers: + 3 * 2 * 250 M * 64 B = 96 GB
+    tot, _ = A.algorithmic_bytes_shape((8, 8), (8, 8), 100, 47, 2450000, 61900000)
+    req, per = A.request_bytes_shape((8, 8), (8, 8), 100, 47, 2450000, 61900000)
+    assert req == tot
+    req5, per5 = A.request_bytes_shape((4, 4), (8, 8), 128, 47, 10_000_000, 250_000_000, dtype="bf16")
+    assert abs(req5 - bf - 3 * 2 * 250_000_000 * 64) < 1.0 and abs(sum(per5.values()) - req5) < 1e-3
+    reqf, _ = A.request_bytes_shape((4, 4), (8, 8), 128, 47, 10_000_000, 250_000_000)       # fp32 rows at H*D = 32 are exactly one request
+    assert reqf == f32
 
 
 def test_release_library_does_not_contain_the_experiment_switch():

@@ -82,21 +82,32 @@ SNIPPET = """
 """
 
 
-def _run(env, seed, cases, tag):
-    code = textwrap.dedent(SNIPPET.format(root=ROOT, tests=os.path.join(ROOT, "tests"), seed=seed, cases=cases, tag=tag))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+SETTINGS = [({}, ""), ({"GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"}, " groups, tiny segments"),
+            ({"GAT_PULL_GROUPS": "0", "GAT_PULL_LAST": "0"}, " waves"), ({"GAT_ROWGROUP": "0"}, " chunked"),
+            ({"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"}, " last-layer records, groups"),
+            ({"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "0", "GAT_ROWGROUP": "0"}, " last-layer records, waves, chunked"),
+            ({"GAT_FUSE_LAST": "1", "GAT_PULL_LAST": "1"}, " last layer fused per row"),
+            # slot-parallel source-major pass (gat_csc.hip "runs") forced, gfull and node-record variants, short runs
+            ({"GAT_PULL_RUNS": "1", "GAT_PULL_RUN": "32", "GAT_PULL_LAST": "0"}, " slot runs of 32"),
+            ({"GAT_PULL_RUNS": "1", "GAT_PULL_LAST": "1", "GAT_SEG_EDGES": "16"}, " slot runs, last-layer records"),
+            ({"GAT_PULL_RUNS": "1", "GAT_BWD_STASH": "0"}, " slot runs, message rows")]
+CASES = 9
 
 
-# 9 switch settings x 9 checked cases (ill-conditioned draws are redrawn, not forgiven: VERDICT r3 / ADVICE r3)
-@pytest.mark.parametrize("env,tag", [({}, ""), ({"GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"}, " groups, tiny segments"),
-                                     ({"GAT_PULL_GROUPS": "0", "GAT_PULL_LAST": "0"}, " waves"), ({"GAT_ROWGROUP": "0"}, " chunked"),
-                                     ({"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "1", "GAT_GPL_HEAVY": "16", "GAT_SEG_EDGES": "16"}, " last-layer records, groups"),
-                                     ({"GAT_PULL_LAST": "1", "GAT_PULL_GROUPS": "0", "GAT_ROWGROUP": "0"}, " last-layer records, waves, chunked"),
-                                     ({"GAT_FUSE_LAST": "1", "GAT_PULL_LAST": "1"}, " last layer fused per row"),
-                                     # slot-parallel source-major pass (gat_csc.hip "runs") forced, gfull and node-record variants, short runs
-                                     ({"GAT_PULL_RUNS": "1", "GAT_PULL_RUN": "32", "GAT_PULL_LAST": "0"}, " slot runs of 32"),
-                                     ({"GAT_PULL_RUNS": "1", "GAT_PULL_LAST": "1", "GAT_SEG_EDGES": "16"}, " slot runs, last-layer records"),
-                                     ({"GAT_PULL_RUNS": "1", "GAT_BWD_STASH": "0"}, " slot runs, message rows")])
-def test_random_small_cases(env, tag):
-    _run(env, 20260 + len(tag), 9, tag)
+@pytest.fixture(scope="module")
+def fuzz_runs():
+    """All settings at once, five subprocesses at a time (tests/conftest.py run_snippets_parallel): each is ~35 s of CPU oracle +
+    fp64 reference around a few milliseconds of GPU work."""
+    from conftest import run_snippets_parallel
+    jobs = {}
+    for env, tag in SETTINGS:
+        code = textwrap.dedent(SNIPPET.format(root=ROOT, tests=os.path.join(ROOT, "tests"), seed=20260 + len(tag), cases=CASES, tag=tag))
+        jobs[tag] = (code, env)
+    return run_snippets_parallel(jobs)
+
+
+# 10 switch settings x 9 checked cases (ill-conditioned draws are redrawn, not forgiven: VERDICT r3 / ADVICE r3)
+@pytest.mark.parametrize("env,tag", SETTINGS)
+def test_random_small_cases(fuzz_runs, env, tag):
+    out = fuzz_runs[tag]
+    assert out.returncode == 0 and "OK ran %d" % CASES in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -3,6 +3,7 @@ seeded inputs.  Tolerances (north_star): CSR->COO bit-exact; attentio
 every gradient tensor within 1e-4 of its max-abs, LeakyReLU kinks accounted for entry by entry
 (tests/parity.py); achieved errors are recorded in gpurun_out/parity_errors.json."""
 import os
+import textwrap
 
 import numpy as np
 import pytest
@@ -352,14 +353,14 @@ def test_release_library_ignores_gat_dbg(tmp_path):
         print("SWITCHES<" + A.switches() + ">")
     """)
     outs = []
-    for tag, env in (("plain", {}), ("dbg1", {"GAT_DBG": "1"}), ("dbg3", {"GAT_DBG": "3", "GAT_PULL_LAST": "1"})):
+    for tag, env in (("plain", {}), ("dbg1", {"GAT_DBG": "1"}), ("dbg3", {"GAT_DBG": "3", "GAT_PULL_LAST": "0"})):       # (0 is this size's default: same kernels)
         f = str(tmp_path / (tag + ".npz"))
         env_all = {k: v for k, v in os.environ.items() if k not in ("GAT_DBG", "GATV2_LIB")}
         out = subprocess.run([sys.executable, "-c", code, f], env=dict(env_all, **env), capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "SWITCHES<" in out.stdout, out.stderr[-2000:]
         assert "GAT_DBG" not in out.stdout and "experiment" not in out.stdout
         if tag == "dbg3":
-            assert "GAT_PULL_LAST=1" in out.stdout                      # choice switches ARE reported
+            assert "GAT_PULL_LAST=0" in out.stdout                      # choice switches ARE reported
         outs.append(np.load(f)["g"])
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
@@ -449,7 +450,7 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
             ctx.close()
 
 
-@pytest.mark.parametrize("env", [{"GAT_PACKED": "0", "GAT_BWD_STASH": "0"}, {"GAT_CPL": "2", "GAT_BWD_STASH": "0"},
+AB_SWITCHES = [{"GAT_PACKED": "0", "GAT_BWD_STASH": "0"}, {"GAT_CPL": "2", "GAT_BWD_STASH": "0"},
                                  {"GAT_BWD_STASH": "0"}, {"GAT_BWD_ATOMICS": "1"},
                                  {"GAT_FWD_WAVES": "4", "GAT_GPL_WAVES": "1", "GAT_SEG_EDGES": "64"},
                                  {"GAT_GPL_HEAVY": "64"},
@@ -477,37 +478,58 @@ def test_every_fast_path_shape(pkg, orc, hd, d):
                                  # slot-parallel source-major pass ("runs": the default on short lists / shards) forced on this graph's long
                                  # lists (a 700-slot hub source crosses many runs), both g variants, record and message-row layers
                                  {"GAT_PULL_RUNS": "1", "GAT_PULL_RUN": "32", "GAT_PULL_LAST": "0"}, {"GAT_PULL_RUNS": "1", "GAT_PULL_LAST": "1"},
-                                 {"GAT_PULL_RUNS": "1", "GAT_BWD_STASH": "0"}, {"GAT_PULL_RUNS": "0", "GAT_PULL_GROUPS": "1"}])
-def test_ab_switches_stay_correct(pkg, orc, env):
-    """The A/B switches of DESIGN §7 select other kernels / launch shapes for the SAME math: each must still
+                                 {"GAT_PULL_RUNS": "1", "GAT_BWD_STASH": "0"}, {"GAT_PULL_RUNS": "0", "GAT_PULL_GROUPS": "1"}]
+
+AB_CODE = textwrap.dedent(f"""
+    import sys, numpy as np
+    sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+    sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+    import __graft_entry__ as entry
+    import parity
+    from conftest import small_graph
+    pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
+    rng = np.random.default_rng(5)
+    rp, ci = small_graph(rng, 260, 2600, hub=(9, 700), empty=(0, 3))
+    x = rng.standard_normal((260, 12)).astype(np.float32)
+    lab = rng.integers(0, 4, 260).astype(np.int32); lab[0] = 3
+    for heads, outdims in (([8, 8], [8, 8]), ([4, 2], [4, 8])):
+        cfg = orc.Config(heads, outdims, 12, 4)
+        W, a, Wo = orc.xavier_params(cfg, 6)
+        ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
+        ctx = pkg.GatContext(heads, outdims, 12, 4)
+        ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
+        for g, arr in enumerate((W, a, Wo)): ctx.params_set(g, arr)
+        ctx.zero_grad(); loss, correct = ctx.step()
+        assert abs(loss - ref.loss_sum_f64) / 260 < 1e-4 and correct == ref.n_correct
+        assert np.abs(ctx.tap(A.TAP_HPRE, 1) - ref.taps["hpre"][1]).max() < 1e-4 * max(1.0, np.abs(ref.taps["hpre"][1]).max())
+        parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx)
+        ctx.close()
+    parity.flush()
+    print("OK")
+""")
+EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "graph-attention-network-gatv2-_amd", "libgatv2_hip_exp.so")
+
+
+@pytest.fixture(scope="module")
+def ab_runs():
+    """Every switch setting in its own subprocess (they are read once per process), five at a time (conftest.run_snippets_parallel)."""
+    from conftest import run_snippets_parallel
+    jobs = {}
+    for i, env in enumerate(AB_SWITCHES):
+        env = dict(env)
+        if env.get("GATV2_LIB") == "exp":
+            if not os.path.exists(EXP_LIB):
+                continue
+            env["GATV2_LIB"] = EXP_LIB
+        jobs[i] = (AB_CODE, env)
+    return run_snippets_parallel(jobs, timeout=300)
+
+
+@pytest.mark.parametrize("idx", range(len(AB_SWITCHES)), ids=[",".join(f"{k}={v}" for k, v in e.items()) for e in AB_SWITCHES])
+def test_ab_switches_stay_correct(ab_runs, idx):
+    """The A/B switches of DESIGN §8 select other kernels / launch shapes for the SAME math: each must still
     match the oracle (they are read once per process, hence a subprocess)."""
-    import subprocess, sys, textwrap
-    code = textwrap.dedent(f"""
-        import sys, numpy as np
-        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
-        sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
-        import __graft_entry__ as entry
-        import parity
-        from conftest import small_graph
-        pkg = entry.load_package(); orc = entry.load_oracle(); A = pkg.abi
-        rng = np.random.default_rng(5)
-        rp, ci = small_graph(rng, 260, 2600, hub=(9, 700), empty=(0, 3))
-        x = rng.standard_normal((260, 12)).astype(np.float32)
-        lab = rng.integers(0, 4, 260).astype(np.int32); lab[0] = 3
-        for heads, outdims in (([8, 8], [8, 8]), ([4, 2], [4, 8])):
-            cfg = orc.Config(heads, outdims, 12, 4)
-            W, a, Wo = orc.xavier_params(cfg, 6)
-            ref = orc.step(cfg, rp, ci, lab, x, W, a, Wo)
-            ctx = pkg.GatContext(heads, outdims, 12, 4)
-            ctx.set_graph(rp, ci); ctx.set_features(x); ctx.set_labels(lab)
-            for g, arr in enumerate((W, a, Wo)): ctx.params_set(g, arr)
-            ctx.zero_grad(); loss, correct = ctx.step()
-            assert abs(loss - ref.loss_sum_f64) / 260 < 1e-4 and correct == ref.n_correct
-            assert np.abs(ctx.tap(A.TAP_HPRE, 1) - ref.taps["hpre"][1]).max() < 1e-4 * max(1.0, np.abs(ref.taps["hpre"][1]).max())
-            parity.check_context_gradients(orc, A, cfg, rp, ci, lab, x, W, a, Wo, ref, ctx)
-            ctx.close()
-        parity.flush()
-        print("OK")
-    """)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    if idx not in ab_runs:
+        pytest.skip("experiment library not built (make -C graph-attention-network-gatv2-_amd/csrc experiments)")
+    out = ab_runs[idx]
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
