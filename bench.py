@@ -113,6 +113,7 @@ def cpu_baseline(pkg, workload, heads, outdims, sample_scale):
     return {
         "value": ds["e"] / t, "unit": "edges/s", "cores": orc.lib().orc_num_threads(), "kind": "port",
         "cpu_model": cpu_model(), "build_flags": orc.build_flags(),
+        "host_cpus": f"{os.cpu_count()} logical CPUs visible; OpenMP team = the CPUs this job may use (affinity capped by the cgroup quota): {orc.effective_cpus()}",
         "sample": f"{workload}-law graph scaled to {ds['n']} nodes / {ds['e']} edges / {ds['f']} feat, "
                   f"1 step fwd+bwd in {t:.2f} s (oracle literal mode, OpenMP); the literal algorithm's softmax backward is "
                   f"O(sum deg^2), which grows faster than E: the full graph would run at FEWER edges/s than this sample",

@@ -51,10 +51,31 @@ def build_flags() -> str:
             else "-O2 -mavx2 -mfma -ffp-contract=fast -fopenmp")
 
 
+def effective_cpus() -> int:
+    """Host CPUs this process may really use: the affinity mask capped by the cgroup CPU quota.  (The GPU boxes of the build pool show
+    256 CPUs and grant a job 16 of them through cpu.max: an OpenMP team of 256 on a 16-CPU quota is throttled to FEWER operations
+    per second than a team of 16 — measured — so the oracle sizes its team to the quota, and the CPU baselines report that number.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p_ > 0:
+                n = min(n, max(1, int(q / p_ + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    if "OMP_NUM_THREADS" not in os.environ:            # before libgomp is loaded: the team size of every parallel region
+        os.environ["OMP_NUM_THREADS"] = str(effective_cpus())
     L = C.CDLL(build())
     i, f = C.c_int, C.c_float
     sig = {

@@ -72,6 +72,9 @@ def run_snippets_parallel(jobs, workers=5, timeout=900):
 
     def one(item):
         key, (code, env) = item
+        # small cases: the oracle's OpenMP loops are microseconds of work each — with one thread per host core (hundreds) on a box
+        # that grants this job a fraction of them, a setting took ~38 s of thread start-up instead of ~2 s
+        env = dict({"OMP_NUM_THREADS": "4", "OPENBLAS_NUM_THREADS": "4", "MKL_NUM_THREADS": "4"}, **env)
         try:
             return key, subprocess.run([_sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=timeout)
         except subprocess.TimeoutExpired as e:
