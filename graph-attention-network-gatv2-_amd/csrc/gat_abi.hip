@@ -178,7 +178,6 @@ struct gat_ctx {
     int4* items = nullptr; int4* slot_info = nullptr;
     float* part_acc = nullptr; float* part_mz = nullptr;
     float* ga_partial = nullptr; int32_t ga_blocks = 0;
-    uint32_t* tile_counters = nullptr; int64_t n_tile_counters = 0;      // arrival counters of the latency-sized split-K projection (zero between launches)
     float* gw_scratch = nullptr; int64_t gw_scratch_floats = 0; std::vector<int64_t> gw_off;       // [L] first float of each layer's grad_w slab region
     float* hb_partial = nullptr;
     double* loss_partial = nullptr; int32_t* correct_partial = nullptr;
@@ -410,19 +409,6 @@ static int ensure_buffers(gat_ctx* c) {
     }
     GAT_TRY(dalloc(c, &c->gw_scratch, gw));
     c->gw_scratch_floats = gw;
-    {   // one arrival counter per 64 x 64 output tile of a split-K projection launch (only launches with a slab scratch use them)
-        int64_t nc = 1;
-        for (int l = 0; l < L; ++l) {
-            const Layer& y = c->layers[l];
-            if (l == 0 && c->Xtab) {
-                if (project_scratch_floats(T, y.F, y.HD, kPartLeft) > 0) nc = std::max(nc, project_tile_counters(T, y.HD, kPartLeft));
-                if (project_scratch_floats(N, y.F, y.HD, kPartRight) > 0) nc = std::max(nc, project_tile_counters(N, y.HD, kPartRight));
-            } else if (project_scratch_floats(N, y.F, y.HD, kPartBoth) > 0) nc = std::max(nc, project_tile_counters(N, y.HD, kPartBoth));
-        }
-        GAT_TRY(dalloc(c, &c->tile_counters, nc));
-        GAT_HIP(hipMemsetAsync(c->tile_counters, 0, (size_t)nc * sizeof(uint32_t), c->stream));
-        c->n_tile_counters = nc;
-    }
     const int C = c->cfg.num_classes, DL = c->layers[L - 1].D;
     GAT_TRY(dalloc(c, &c->hb_partial, (int64_t)head_bwd_blocks(N, C, DL) * C * DL));
     GAT_TRY(dalloc(c, &c->loss_partial, head_blocks(N)));
@@ -802,11 +788,11 @@ int gat_layer_project(gat_ctx* c, int32_t l) {
     Layer& y = c->layers[l];
     Scope t(c, GAT_K_PROJECT);
     if (l == 0 && c->Xtab) {      // replicated input: whole PL table from the table rows, PR from the shard's rows
-        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream, c->tile_counters, c->n_tile_counters));
-        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream, c->tile_counters, c->n_tile_counters);
+        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream));
+        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream);
     }
     float* own_rows = reinterpret_cast<float*>(reinterpret_cast<char*>(y.PL) + c->table_row0 * y.HD * st_bytes(c));
-    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream, c->tile_counters, c->n_tile_counters);
+    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream);
 }
 
 static EdgeFwdArgs plan_forward_edges(gat_ctx* c, int32_t l);

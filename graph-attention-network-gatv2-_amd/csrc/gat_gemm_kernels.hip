@@ -635,122 +635,6 @@ __global__ __launch_bounds__(256) void project_splitk_x3_kernel(ASrcRows as, BSr
             if (orow < M && col < N) out[orow * N + col] = acc[nt][r];
         }
 }
-// Latency-sized form of the same split-K projection (few rows, long K: Cora / Pubmed shapes).  What the kernel
-// above spends its time on at these sizes is not arithmetic (48 MFMAs per wave) but its A operand: every lane loads its row's
-// k-octets straight from HBM, a wave instruction touching 32 different rows (for an odd row pitch with four scalar loads per
-// float4), 16 such instructions per chunk, the same lines again and again through a thrashing L1 — and then a second launch adds
-// the slabs.  Here
-//   * a block is 64 rows x 64 columns x one 128-deep K chunk (80 KiB of LDS: two per CU); both operand chunks are loaded
-//     ROW-MAJOR (consecutive lanes = consecutive k of one row: whole lines per instruction, any alignment) into LDS — A as
-//     fp32 with XOR-swizzled 16-byte chunks (conflict-free fragment reads), B pre-cut into the three piece planes as before;
-//   * each wave computes a 32 x 32 tile with the same k-step / piece-product order as the kernel above, so every slab element
-//     is bit for bit what that kernel produces;
-//   * the LAST block to finish a (row tile, column tile) — an arrival counter per tile, release / acquire fences — adds the
-//     tile's K slabs in ascending chunk order and applies the epilogue: same sums as project_reduce_kernel, no second launch,
-//     deterministic whatever the arrival order.  The counter is reset by the block that consumed it.
-template <bool VEC4, class EP>
-__global__ __launch_bounds__(256) void project_small_x3_kernel(ASrcRows as, BSrcProject bs, float* __restrict__ slabs, uint32_t* __restrict__ counters,
-                                                               int64_t M, int32_t N, int32_t K, EP ep) {
-    constexpr int BM = 64, NW = 64, KC = 128, KS = KC / 16, plane = KS * 2 * NW;
-    extern __shared__ uint4 smem[];                   // Bq [3][KS][2][NW] uint4 (48 KiB) | A [BM][KC] floats (32 KiB)
-    uint4* Bq = smem;
-    float4* Aq = reinterpret_cast<float4*>(smem + 3 * plane);           // [BM][32 chunks], chunk c of row r at r*32 + (c ^ (r & 31))
-    __shared__ int s_last;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, half = lane >> 5;
-    const int64_t r0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * NW;
-    const int k0 = blockIdx.z * KC;
-    const int kc = (K - k0 < KC) ? (K - k0) : KC;
-    // A chunk: thread -> (row, 16-byte chunk), consecutive threads along k
-#pragma unroll
-    for (int it = 0; it < BM * 32 / 256; ++it) {
-        const int idx = tid + 256 * it;
-        const int r = idx >> 5, c = idx & 31, kk = c * 4;
-        int64_t row = r0 + r;
-        row = row < M ? row : M - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (VEC4) {
-            if (kk < kc) v = as.load4(row, k0 + kk);
-        } else {
-            if (kk + 0 < kc) v.x = as.load1(row, k0 + kk + 0);
-            if (kk + 1 < kc) v.y = as.load1(row, k0 + kk + 1);
-            if (kk + 2 < kc) v.z = as.load1(row, k0 + kk + 2);
-            if (kk + 3 < kc) v.w = as.load1(row, k0 + kk + 3);
-        }
-        Aq[r * 32 + (c ^ (r & 31))] = v;
-    }
-    for (int idx = tid; idx < KS * 2 * NW; idx += 256) {   // consecutive threads -> consecutive k-octets of one column (W rows are k-contiguous)
-        const int kh = idx % (KS * 2), n = idx / (KS * 2);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int kk = kh * 8 + j;
-            v[j] = (kk < kc && n0 + n < N) ? bs.at(k0 + kk, n0 + n) : 0.f;
-        }
-        const Pieces p = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
-        Bq[kh * NW + n] = p.hi; Bq[plane + kh * NW + n] = p.mid; Bq[2 * plane + kh * NW + n] = p.lo;
-    }
-    __syncthreads();
-    const int wr = (wave & 1) * 32, wc = (wave >> 1) * 32;
-    v16f acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int ar = wr + li;
-#pragma unroll
-    for (int st = 0; st < KS; ++st) {
-        const int c0 = st * 4 + 2 * half;
-        const Pieces a = split8(Aq[ar * 32 + (c0 ^ (ar & 31))], Aq[ar * 32 + ((c0 + 1) ^ (ar & 31))]);
-        const uint4* bp = Bq + (st * 2 + half) * NW + wc + li;
-        const uint4 bh = bp[0], bm = bp[plane], bl = bp[2 * plane];
-#ifdef GAT_X3_EIGHT_TERMS
-        acc = mfma_bf16(a.lo, bm, acc);
-        acc = mfma_bf16(a.mid, bl, acc);
-#endif
-        acc = mfma_bf16(a.lo, bh, acc);
-        acc = mfma_bf16(a.hi, bl, acc);
-        acc = mfma_bf16(a.mid, bm, acc);
-        acc = mfma_bf16(a.mid, bh, acc);
-        acc = mfma_bf16(a.hi, bm, acc);
-        acc = mfma_bf16(a.hi, bh, acc);
-    }
-    const int ksplit = gridDim.z;
-    const int64_t MN = M * N;
-    if (ksplit == 1) {                                // nothing to add: straight to the epilogue
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t orow = r0 + wr + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int col = n0 + wc + li;
-            if (orow < M && col < N) ep(orow, col, acc[r]);
-        }
-        return;
-    }
-    float* out = slabs + (int64_t)blockIdx.z * MN;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t orow = r0 + wr + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int col = n0 + wc + li;
-        if (orow < M && col < N) out[orow * N + col] = acc[r];
-    }
-    __threadfence();                                  // release: this block's slab tile is visible device-wide before it counts as arrived
-    __syncthreads();
-    uint32_t* cnt = counters + (int64_t)blockIdx.x * gridDim.y + blockIdx.y;
-    if (tid == 0) s_last = (atomicAdd(cnt, 1u) == (uint32_t)(ksplit - 1));
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                  // acquire: the other blocks' slab tiles
-    for (int idx = tid; idx < BM * NW; idx += 256) {
-        const int r = idx / NW, cidx = idx % NW;
-        const int64_t orow = r0 + r;
-        const int col = n0 + cidx;
-        if (orow < M && col < N) {
-            float v = 0.f;
-            for (int z = 0; z < ksplit; ++z) v += __builtin_nontemporal_load(slabs + (int64_t)z * MN + orow * N + col);
-            ep(orow, col, v);
-        }
-    }
-    if (tid == 0) *cnt = 0u;                          // ready for the next launch (stream order separates them)
-}
 template <class EP>
 __global__ __launch_bounds__(256) void project_reduce_kernel(const float* __restrict__ slabs, int32_t ksplit, int64_t M, int32_t N, EP ep) {
     const int64_t total = M * N, stride = (int64_t)gridDim.x * blockDim.x;
@@ -1189,10 +1073,8 @@ int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD, int32_t pa
     return project_wants_splitk(n_rows, N, F) ? (int64_t)((F + 127) / 128) * n_rows * N : 0;
 }
 
-int64_t project_tile_counters(int64_t n_rows, int32_t HD, int32_t part) { return ((n_rows + 63) / 64) * (((part == kPartBoth ? 2 * HD : HD) + 63) / 64); }
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows, int32_t F,
-                   int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s,
-                   uint32_t* counters, int64_t n_counters) {
+                   int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s) {
     const int32_t j0 = part == kPartRight ? HD : 0;
     ASrcRows as{X, F};
     BSrcProject bs{W, F, HD, j0};
@@ -1204,24 +1086,13 @@ int launch_project(const float* X, const float* W, float* PL_rows, float* PR, in
         const int ksplit = (F + 127) / 128;
         const dim3 grid((unsigned)((n_rows + 127) / 128), (unsigned)((N + 127) / 128), (unsigned)ksplit);
         static const bool x3 = [] { const char* e = choice_env("GAT_GEMM_X3"); return !(e && e[0] == '0'); }();       // A/B: 0 = fp32 MFMA
-        // latency-sized form (project_small_x3_kernel: coalesced operand loads through LDS, slabs added by the last block of a tile);
-        // GAT_PROJECT_SMALL=0: the two-launch form below (A/B; the results are bitwise the same)
-        static const bool small_on = [] { const char* e = choice_env("GAT_PROJECT_SMALL"); return !(e && e[0] == '0'); }();
-        if (x3 && small_on && counters != nullptr && n_counters >= ((n_rows + 63) / 64) * ((N + 63) / 64) && ((n_rows + 63) / 64) < 65536) {
-            const dim3 gs((unsigned)((n_rows + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)ksplit);
-            const size_t lds = (size_t)3 * 8 * 2 * 64 * sizeof(uint4) + (size_t)64 * 128 * sizeof(float);
-#define GAT_PSMALL(V4_, BF_)                                                                                           \
-            do {                                                                                                         \
-                allow_big_lds((const void*)project_small_x3_kernel<V4_, EpiProject<BF_>>);                              \
-                hipLaunchKernelGGL((project_small_x3_kernel<V4_, EpiProject<BF_>>), gs, dim3(256), lds, s, as, bs, scratch, counters, n_rows, N, F, \
-                                   EpiProject<BF_>{PL_rows, PR, HD, j0});                                                 \
-            } while (0)
-            if (vec4) { if (pl_bf16) GAT_PSMALL(true, true); else GAT_PSMALL(true, false); }
-            else { if (pl_bf16) GAT_PSMALL(false, true); else GAT_PSMALL(false, false); }
-#undef GAT_PSMALL
-            GAT_HIP(hipGetLastError());
-            return 0;
-        }
+        // MEASURED AND NOT KEPT (profiles/r04/experiments/small_shapes; DESIGN §4 "Round 4"): a latency-sized form of this launch —
+        // 64-row blocks, both operand chunks staged ROW-MAJOR through LDS (whole lines per load instruction instead of 32 rows per
+        // instruction), same slab bits — Cora-shape 186 -> 192 us, Pubmed-shape 246 -> 272 us per step under replay (twice the
+        // blocks, each re-cutting its W chunk; the operand fetch was not the bound: the chunk's unique lines are the same either way
+        // and the CUs' miss throughput caps both); with the slabs added by the LAST block of a tile (arrival counter + device-
+        // scope fences, no second launch) 352 / 610 us: a release / acquire pair per block is an L2 write-back + invalidate on this
+        // 8-XCD part; all loads of the B fill issued before the first is cut: 190 / 247 us (no change).
         if (x3) {
             // 64-column blocks (48 KiB of LDS: three per CU) unless GAT_SPLITK_NT=4: Pubmed-shape 0.311 -> 0.302 ms per step
             static const int nt = [] { const char* e = choice_env("GAT_SPLITK_NT"); return e && atoi(e) == 4 ? 4 : 2; }();

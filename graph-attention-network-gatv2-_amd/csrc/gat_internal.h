@@ -279,12 +279,8 @@ enum : int32_t { kPartBoth = 0, kPartLeft = 1, kPartRight = 2 };
 // needs one), or null; few rows with a long K (Cora / Pubmed shapes) take a split-K path through it.  A scratch smaller than
 // this launch needs (or null) selects the streaming kernel — never an overrun.
 int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD, int32_t part);
-// counters / n_counters: at least project_tile_counters(n_rows, HD, part) zero-initialised words owned by the caller (one arrival
-// counter per 64 x 64 output tile of the latency-sized split-K form, each left at zero again by the launch), or null: the two-launch form
-int64_t project_tile_counters(int64_t n_rows, int32_t HD, int32_t part);
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows,
-                   int32_t F, int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s,
-                   uint32_t* counters = nullptr, int64_t n_counters = 0);
+                   int32_t F, int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s);
 // gradW[j][0:F] += sum_n gPL[n][j] X[n][:],  gradW[j][F:2F] += sum_n gPR[n][j] X[n][:]
 // scratch: at least grad_w_scratch_floats(n_rows, F, HD) floats.
 int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);
