@@ -1099,8 +1099,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
             for (int u = 0; u < U; ++u) v[u] = gather_row_n<HD, N, BF>(A.PL, src[u], cp);
             if constexpr (MSG) {                     // the previous step's message rows (spare row E for padded lanes)
+                if constexpr (DBG != 1) {            // (experiment library, GAT_DBG=1: the walk without its row stores — attribution of the reads)
 #pragma unroll
-                for (int u = 0; u < U; ++u) store_row_n<HD, N, BF>(A.msg, (int)pend_s[u], cp, pend_m[u]);
+                    for (int u = 0; u < U; ++u) store_row_n<HD, N, BF>(A.msg, (int)pend_s[u], cp, pend_m[u]);
+                }
             } else if constexpr (DBG == 3) {                // timing experiment: the step's bytes as ONE 16-B-per-lane store, CSR order
                 const int j0 = b + (st > 0 ? st - 1 : 0) * U;
                 uint4 w4 = make_uint4(pend_w[0], pend_w[1], pend_w[2], pend_w[3]);
@@ -1143,8 +1145,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             }
         }
         if constexpr (MSG) {
+            if constexpr (DBG != 1) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) store_row_n<HD, N, BF>(A.msg, (int)pend_s[u], cp, pend_m[u]);              // the last step's rows
+                for (int u = 0; u < U; ++u) store_row_n<HD, N, BF>(A.msg, (int)pend_s[u], cp, pend_m[u]);          // the last step's rows
+            }
         } else if constexpr (DBG != 1 && DBG != 3) {
 #pragma unroll
             for (int u = 0; u < U; ++u) stream_store(&A.stash[(uint64_t)pend_s[u] * LPE + cp], pend_w[u]);      // the last step's records

@@ -1059,7 +1059,7 @@ int64_t grad_w_kchunk(int64_t n_rows, int32_t F, int32_t M) {
     kchunk = ((kchunk + 31) / 32) * 32;
     // shortest node chunk per block (GAT_GRADW_KMIN, A/B): a block's time is its chain of 16-node tiles (load -> cut into LDS ->
     // barrier -> MFMA), so few rows want short chains and more slabs; many rows never reach this bound
-    static const int kmin = [] { const char* e = choice_env("GAT_GRADW_KMIN"); const int v = e ? atoi(e) : 0; return v >= 32 ? (v / 32) * 32 : 256; }();
+    static const int kmin = [] { const char* e = choice_env("GAT_GRADW_KMIN"); const int v = e ? atoi(e) : 0; return v >= 32 ? (v / 32) * 32 : 128; }();       // 128: Cora-shape 187.7 -> 182.6 us, Pubmed-shape 248 -> 242 us per step (256 before; 64: the same)
     if (kchunk < kmin) kchunk = kmin;
     return kchunk;
 }
