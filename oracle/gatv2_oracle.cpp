@@ -54,6 +54,15 @@ int orc_num_threads() {
     return 1;
 #endif
 }
+// team size of the following parallel regions (oracle.py sizes it to the CPUs the job may really use: a process that loaded an
+// OpenMP runtime before this library — torch does — has already read OMP_NUM_THREADS)
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 // ---- a1: csr_to_coo_kernel, E:67-84 -------------------------------------------------
 void orc_csr_to_coo(const int* row_ptr, const int* col_idx, int* src, int* dst, int N) {

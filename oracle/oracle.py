@@ -74,9 +74,15 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
-    if "OMP_NUM_THREADS" not in os.environ:            # before libgomp is loaded: the team size of every parallel region
+    user_threads = os.environ.get("OMP_NUM_THREADS")
+    if user_threads is None:                           # before libgomp is loaded: the team size of every parallel region
         os.environ["OMP_NUM_THREADS"] = str(effective_cpus())
     L = C.CDLL(build())
+    try:                                               # ... and explicitly: an OpenMP runtime loaded earlier (torch) has read the variable already
+        L.orc_set_num_threads.argtypes = [C.c_int]; L.orc_set_num_threads.restype = None
+        L.orc_set_num_threads(int(user_threads) if user_threads and user_threads.isdigit() else effective_cpus())
+    except AttributeError:
+        pass
     i, f = C.c_int, C.c_float
     sig = {
         "orc_num_threads": ([], i),
