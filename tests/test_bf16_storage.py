@@ -117,10 +117,14 @@ def test_bf16_heavy_source_chunks_equal_unchunked(tmp_path):
         np.save(sys.argv[1], np.concatenate(out))
     """)
     res = []
-    for tag, heavy in (("chunked", "256"), ("flat", "1000000000")):
+    # ... and the slot-parallel forms of both passes (gat_csc.hip "runs": bf16 g rows in the record pull, bf16 message rows in the
+    # sum) forced on the same graph: again only the summation order may differ
+    for tag, extra in (("chunked", {"GAT_GPL_HEAVY": "256"}), ("flat", {"GAT_GPL_HEAVY": "1000000000"}),
+                       ("runs", {"GAT_PULL_RUNS": "1", "GAT_PULL_RUN": "32"}), ("runs64", {"GAT_PULL_RUNS": "1"})):
         f = str(tmp_path / f"{tag}.npy")
-        env = dict(os.environ, GAT_GPL_HEAVY=heavy)
+        env = dict(os.environ, OMP_NUM_THREADS="4", **extra)
         r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(f))
-    assert np.abs(res[0] - res[1]).max() <= 1e-5 * np.abs(res[1]).max()
+    for other in (res[0], res[2], res[3]):
+        assert np.abs(other - res[1]).max() <= 1e-5 * np.abs(res[1]).max()
