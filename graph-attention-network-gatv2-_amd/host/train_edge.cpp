@@ -14,6 +14,8 @@
 // "host" stages them through shared memory and lets ranks share a GPU — for testing).  Every rank
 // reads the dataset, keeps its destination range (host/shard_plan.h) and the replicated input
 // features; rank 0 prints.  Same numbers as one GPU up to fp32 summation order.
+// --halo 0|1|2 (with --ranks): the table exchanges move only the rows the receiving shard's edges reference (gat_comm_option
+// GAT_COMM_HALO; 2 = only where fewer than half of the rows would travel).  Same numbers as the full exchange.
 // --dtype f32|bf16: storage type of the gathered / exchanged source table and the per-edge message
 // rows (arithmetic stays fp32).
 #include <algorithm>
@@ -58,6 +60,7 @@ struct Options {
     bool cache = false;
     int ranks = 1;
     std::string transport = "rccl";
+    int halo = 0;
     std::string dtype = "f32";
     std::string train_mask, val_mask;     // text files of N 0/1 values (beyond the reference: README R:134 "later")
 };
@@ -128,6 +131,9 @@ Options parse_args(int argc, char** argv) {
         } else if (a == "--dtype" && has_val) {
             o.dtype = argv[++i];
             if (o.dtype != "f32" && o.dtype != "bf16") die("Invalid dtype choice. Use 'f32' or 'bf16'\n");
+        } else if (a == "--halo" && has_val) {
+            o.halo = std::stoi(argv[++i]);
+            if (o.halo < 0 || o.halo > 2) die("Invalid halo choice. Use 0, 1 or 2\n");
         } else if (a == "--transport" && has_val) {
             o.transport = argv[++i];
             if (o.transport != "rccl" && o.transport != "host") die("Invalid transport choice. Use 'rccl' or 'host'\n");
@@ -377,9 +383,10 @@ int run(const Options& o, const RankEnv& env) {
         } else {
             int64_t hd_max = 0;
             for (int l = 0; l < L; ++l) hd_max = std::max<int64_t>(hd_max, (int64_t)o.heads[l] * o.outdims[l]);
-            const int64_t bytes = std::max<int64_t>(plan.n_table() * hd_max, nW + nA + nWo + 3) * (int64_t)sizeof(float);
+            const int64_t bytes = std::max<int64_t>(plan.n_table() * hd_max + 64, nW + nA + nWo + 3) * (int64_t)sizeof(float);   // (+ 64: block offsets of a halo exchange)
             check(gat_comm_init_host(ctx, env.world, env.rank, env.shm_name.c_str(), bytes), "gat_comm_init_host");
         }
+        if (o.halo != 0) check(gat_comm_option(ctx, GAT_COMM_HALO, o.halo), "gat_comm_option(GAT_COMM_HALO)");      // collective: every rank
     }
     // the 4 GiB cliff of gatv2_abi.h "Limits" is never silent: ask every layer which kernels it runs on
     if (env.rank == 0) {

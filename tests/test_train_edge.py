@@ -139,6 +139,11 @@ def test_ranks_match_single_process(pkg, tmp_path, ranks):
     p1 = np.fromfile(tmp_path / "p1.bin", dtype=np.float32)
     pN = np.fromfile(tmp_path / "pN.bin", dtype=np.float32)
     assert p1.shape == pN.shape and np.abs(p1 - pN).max() < 1e-4 * max(1.0, np.abs(p1).max())
+    # --halo 1: only the rows each shard's edges reference travel; the epochs end at the SAME parameters, bit for bit
+    halo = run(base + ["--ranks", str(ranks), "--transport", "host", "--halo", "1", "--dump-params", str(tmp_path / "pH.bin")])
+    assert halo.returncode == 0, halo.stderr
+    assert re.findall(pat, halo.stdout) == re.findall(pat, many.stdout)
+    assert np.array_equal(np.fromfile(tmp_path / "pH.bin", dtype=np.float32), pN)
 
 
 @pytest.mark.gpu
