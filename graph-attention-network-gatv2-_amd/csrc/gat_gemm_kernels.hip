@@ -561,9 +561,18 @@ __global__ __launch_bounds__(256) void project_splitk_kernel(ASrcRows as, BSrcPr
         }
 }
 // the same block shape on the bf16 pipe (three-piece operands: rowgemm_x3_kernel); B chunk = 3 piece planes in LDS (96 KiB)
+#ifdef GAT_EXPERIMENTS
+#define GAT_ABLATE_PARAM , int ablate
+#define GAT_ABLATE(bit) ((ablate & (bit)) != 0)
+#else
+#define GAT_ABLATE_PARAM
+#define GAT_ABLATE(bit) false
+#endif
+// (experiment library: GAT_DBG_SPLITK = bit mask of parts to SKIP — 1 A loads, 2 B fill, 4 MFMA loop, 8 slab stores — wrong results,
+//  where the block's time goes: DESIGN §4 "Round 4")
 template <bool VEC4, int NT>
 __global__ __launch_bounds__(256) void project_splitk_x3_kernel(ASrcRows as, BSrcProject bs, float* __restrict__ slabs,
-                                                                int64_t M, int32_t N, int32_t K) {
+                                                                int64_t M, int32_t N, int32_t K GAT_ABLATE_PARAM) {
     constexpr int NW = NT * 32, KC = 128, KS = KC / 16, plane = KS * 2 * NW;
     extern __shared__ uint4 Bq[];                     // [3][KS][2][NW]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -580,6 +589,7 @@ __global__ __launch_bounds__(256) void project_splitk_x3_kernel(ASrcRows as, BSr
         for (int q = 0; q < 2; ++q) {
             const int kk = st * 16 + 8 * half + 4 * q;
             af[st][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (GAT_ABLATE(1)) continue;
             if constexpr (VEC4) {
                 if (kk < kc) af[st][q] = as.load4(row, k0 + kk);
             } else {
@@ -590,13 +600,16 @@ __global__ __launch_bounds__(256) void project_splitk_x3_kernel(ASrcRows as, BSr
             }
         }
     for (int idx = threadIdx.x; idx < KS * 2 * NW; idx += 256) {   // consecutive threads -> consecutive k-octets of one column
+        if (GAT_ABLATE(2)) break;
         const int kh = idx % (KS * 2), n = idx / (KS * 2);
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int kk = kh * 8 + j;
-            v[j] = (kk < kc && n0 + n < N) ? bs.at(k0 + kk, n0 + n) : 0.f;
+            if (GAT_ABLATE(16)) v[j] = (float)(kk + n) * 0.001f;          // (experiment: no loads)
+            else v[j] = (kk < kc && n0 + n < N) ? bs.at(k0 + kk, n0 + n) : 0.f;
         }
+        if (GAT_ABLATE(32)) { if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] == 12345.678f) Bq[0] = make_uint4(1u, 2u, 3u, 4u); continue; }   // (experiment: loads only)
         const Pieces p = split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
         Bq[kh * NW + n] = p.hi; Bq[plane + kh * NW + n] = p.mid; Bq[2 * plane + kh * NW + n] = p.lo;
     }
@@ -608,6 +621,7 @@ __global__ __launch_bounds__(256) void project_splitk_x3_kernel(ASrcRows as, BSr
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 #pragma unroll
     for (int st = 0; st < KS; ++st) {
+        if (GAT_ABLATE(4)) break;
         const Pieces a = split8(af[st][0], af[st][1]);
         const uint4* bp = Bq + (st * 2 + half) * NW + li;
 #pragma unroll
@@ -626,6 +640,7 @@ __global__ __launch_bounds__(256) void project_splitk_x3_kernel(ASrcRows as, BSr
         }
     }
     float* out = slabs + (int64_t)blockIdx.z * M * N;
+    if (GAT_ABLATE(8)) { if (acc[0][0] == 12345.678f) out[0] = acc[0][1]; return; }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1092,20 +1107,32 @@ int launch_project(const float* X, const float* W, float* PL_rows, float* PR, in
         // blocks, each re-cutting its W chunk; the operand fetch was not the bound: the chunk's unique lines are the same either way
         // and the CUs' miss throughput caps both); with the slabs added by the LAST block of a tile (arrival counter + device-
         // scope fences, no second launch) 352 / 610 us: a release / acquire pair per block is an L2 write-back + invalidate on this
-        // 8-XCD part; all loads of the B fill issued before the first is cut: 190 / 247 us (no change).
+        // 8-XCD part; all loads of the B fill issued before the first is cut: 190 / 247 us (no change); the W chunk loaded with two
+        // 16-byte loads per k-octet instead of eight scalar ones: 41.1 vs 40.5-42.1 us for the kernel (no change).  Where the kernel's
+        // 40.5 us go on the Pubmed shape (tools/splitk_ablate.sh, experiment library, parts of the block skipped): nothing but the launch
+        // of its 1,240 blocks 5.2; without A loads 38.9, without the W fill 27.5 (fill from constants: 32.7; loads without the cut: 41.3),
+        // without the MFMA loop 35.8, without the slab stores 34.0 — the block is a chain of its W-chunk load latency, the cut, the
+        // barrier, 96 MFMAs and 32 store instructions per lane at 12 waves per CU, not a throughput problem of any one part.
         if (x3) {
             // 64-column blocks (48 KiB of LDS: three per CU) unless GAT_SPLITK_NT=4: Pubmed-shape 0.311 -> 0.302 ms per step
             static const int nt = [] { const char* e = choice_env("GAT_SPLITK_NT"); return e && atoi(e) == 4 ? 4 : 2; }();
             const size_t lds = (size_t)3 * 8 * 2 * (nt * 32) * sizeof(uint4);
             if (nt == 4) { allow_big_lds((const void*)project_splitk_x3_kernel<true, 4>); allow_big_lds((const void*)project_splitk_x3_kernel<false, 4>); }
             const dim3 grid3((unsigned)((n_rows + 127) / 128), (unsigned)((N + nt * 32 - 1) / (nt * 32)), (unsigned)ksplit);
+#ifdef GAT_EXPERIMENTS
+            static const int ablate = [] { const char* e = getenv("GAT_DBG_SPLITK"); return e ? atoi(e) : 0; }();
+#define GAT_ABLATE_ARG , ablate
+#else
+#define GAT_ABLATE_ARG
+#endif
             if (nt == 4) {
-                if (vec4) hipLaunchKernelGGL((project_splitk_x3_kernel<true, 4>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
-                else hipLaunchKernelGGL((project_splitk_x3_kernel<false, 4>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+                if (vec4) hipLaunchKernelGGL((project_splitk_x3_kernel<true, 4>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F GAT_ABLATE_ARG);
+                else hipLaunchKernelGGL((project_splitk_x3_kernel<false, 4>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F GAT_ABLATE_ARG);
             } else {
-                if (vec4) hipLaunchKernelGGL((project_splitk_x3_kernel<true, 2>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
-                else hipLaunchKernelGGL((project_splitk_x3_kernel<false, 2>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
+                if (vec4) hipLaunchKernelGGL((project_splitk_x3_kernel<true, 2>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F GAT_ABLATE_ARG);
+                else hipLaunchKernelGGL((project_splitk_x3_kernel<false, 2>), grid3, dim3(256), lds, s, as, bs, scratch, n_rows, N, F GAT_ABLATE_ARG);
             }
+#undef GAT_ABLATE_ARG
         } else {
             const size_t lds = (size_t)(128 * 128) * sizeof(float);
             if (vec4) hipLaunchKernelGGL(project_splitk_kernel<true>, grid, dim3(256), lds, s, as, bs, scratch, n_rows, N, F);
