@@ -132,6 +132,8 @@ struct gat_ctx {
     int64_t n_labels = 0;                           // length the labels were set with
     double* eval_loss = nullptr; int32_t* eval_cnt = nullptr;      // block partials of gat_eval_mask
     float* X0 = nullptr;
+    int32_t ld0 = 0;                                // floats between rows of X0 / Xtab: in_dim rounded up to a multiple of 4 (zeros behind
+                                                    // column in_dim), so that an odd in_dim — Cora's 1,433 — still gets 16-byte loads
     float* Xtab = nullptr;                          // [n_table][in_dim] replicated layer-0 input (gat_set_source_features)
     int64_t nW = 0, nA = 0, nWo = 0;
     float* params = nullptr;   // [W | a | Wo]
@@ -261,6 +263,17 @@ static float* gW_of(gat_ctx* c, int l) { return c->grads + c->layers[l].w_off; }
 static float* ga_of(gat_ctx* c, int l) { return c->grads + c->nW + c->layers[l].a_off; }
 static float* gWo_of(gat_ctx* c) { return c->grads + c->nW + c->nA; }
 static const float* Xin_of(gat_ctx* c, int l) { return l == 0 ? c->X0 : c->layers[l - 1].hout; }
+static int32_t ldX_of(gat_ctx* c, int l) { return l == 0 ? c->ld0 : c->layers[l].F; }
+// rows of in_dim floats -> rows of ld0 floats with zeros behind column in_dim
+static int upload_rows_padded(gat_ctx* c, float* dst, const float* src, int64_t n_rows, int32_t in_dim, hipMemcpyKind kind) {
+    if (c->ld0 == in_dim) {
+        GAT_HIP(hipMemcpyAsync(dst, src, (size_t)n_rows * in_dim * sizeof(float), kind, c->stream));
+        return 0;
+    }
+    GAT_HIP(hipMemsetAsync(dst, 0, (size_t)n_rows * c->ld0 * sizeof(float), c->stream));
+    GAT_HIP(hipMemcpy2DAsync(dst, (size_t)c->ld0 * sizeof(float), src, (size_t)in_dim * sizeof(float), (size_t)in_dim * sizeof(float), (size_t)n_rows, kind, c->stream));
+    return 0;
+}
 static float* gPL_of(gat_ctx* c, int l) { return (c->ov_active && (l & 1)) ? c->gPL_alt : c->gPL; }
 static float* gPR_of(gat_ctx* c, int l) { return (c->ov_active && (l & 1)) ? c->gPR_alt : c->gPR; }
 
@@ -581,8 +594,9 @@ static int set_features_common(gat_ctx* c, const float* x, int64_t n_rows, int32
     if (!c || !x) return fail(GAT_E_INVALID, "gat_set_features: null argument");
     if (in_dim != c->cfg.in_dim) return fail(GAT_E_INVALID, "gat_set_features: in_dim differs from the config");
     if (c->have_graph && n_rows != c->n_rows) return fail(GAT_E_INVALID, "gat_set_features: row count differs from the graph");
-    if (!c->X0) GAT_TRY(dalloc(c, &c->X0, n_rows * in_dim));
-    GAT_HIP(hipMemcpyAsync(c->X0, x, (size_t)n_rows * in_dim * sizeof(float), kind, c->stream));
+    c->ld0 = (in_dim + 3) / 4 * 4;
+    if (!c->X0) GAT_TRY(dalloc(c, &c->X0, n_rows * c->ld0));
+    GAT_TRY(upload_rows_padded(c, c->X0, x, n_rows, in_dim, kind));
     GAT_HIP(hipStreamSynchronize(c->stream));
     c->have_x = true;
     return ensure_buffers(c);
@@ -604,10 +618,11 @@ static int set_source_features_common(gat_ctx* c, const float* x, int64_t n_tabl
     if (n_table != c->n_table) return fail(GAT_E_INVALID, "gat_set_source_features: row count differs from the source table");
     if (c->buffers_ready) return fail(GAT_E_STATE, "gat_set_source_features: call before the features/labels complete the context");
     if (c->X0) return fail(GAT_E_STATE, "gat_set_source_features: features already set (the table replaces gat_set_features)");
-    GAT_TRY(dalloc(c, &c->Xtab, n_table * in_dim));
-    GAT_HIP(hipMemcpyAsync(c->Xtab, x, (size_t)n_table * in_dim * sizeof(float), kind, c->stream));
+    c->ld0 = (in_dim + 3) / 4 * 4;
+    GAT_TRY(dalloc(c, &c->Xtab, n_table * c->ld0));
+    GAT_TRY(upload_rows_padded(c, c->Xtab, x, n_table, in_dim, kind));
     GAT_HIP(hipStreamSynchronize(c->stream));
-    c->X0 = c->Xtab + c->table_row0 * in_dim;      // the shard's own rows are rows table_row0.. of the table
+    c->X0 = c->Xtab + c->table_row0 * c->ld0;      // the shard's own rows are rows table_row0.. of the table
     c->have_x = true;
     return ensure_buffers(c);
 }
@@ -788,11 +803,11 @@ int gat_layer_project(gat_ctx* c, int32_t l) {
     Layer& y = c->layers[l];
     Scope t(c, GAT_K_PROJECT);
     if (l == 0 && c->Xtab) {      // replicated input: whole PL table from the table rows, PR from the shard's rows
-        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream));
-        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream);
+        GAT_TRY(launch_project(c->Xtab, W_of(c, l), y.PL, nullptr, c->n_table, y.F, y.HD, kPartLeft, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream, c->ld0));
+        return launch_project(c->X0, W_of(c, l), nullptr, y.PR, c->n_rows, y.F, y.HD, kPartRight, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream, c->ld0);
     }
     float* own_rows = reinterpret_cast<float*>(reinterpret_cast<char*>(y.PL) + c->table_row0 * y.HD * st_bytes(c));
-    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream);
+    return launch_project(Xin_of(c, l), W_of(c, l), own_rows, y.PR, c->n_rows, y.F, y.HD, kPartBoth, bf16(c), c->gw_scratch, c->gw_scratch_floats, c->stream, ldX_of(c, l));
 }
 
 static EdgeFwdArgs plan_forward_edges(gat_ctx* c, int32_t l);
@@ -925,10 +940,10 @@ static int backward_grad_w(gat_ctx* c, int32_t l, hipStream_t st) {
     const float* gPL_rows = gPL_of(c, l) + c->table_row0 * y.HD;
     Scope t(c, GAT_K_GRAD_W, st);
     if (l == 0 && c->Xtab) {  // partial gPL over the whole table x replicated input; the gradient all-reduce sums shards
-        GAT_TRY(launch_grad_w(gPL_of(c, l), nullptr, c->Xtab, gW_of(c, l), c->gw_scratch, c->n_table, y.F, y.HD, kPartLeft, st));
-        return launch_grad_w(nullptr, gPR_of(c, l), c->X0, gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, kPartRight, st);
+        GAT_TRY(launch_grad_w(gPL_of(c, l), nullptr, c->Xtab, gW_of(c, l), c->gw_scratch, c->n_table, y.F, y.HD, kPartLeft, st, c->ld0));
+        return launch_grad_w(nullptr, gPR_of(c, l), c->X0, gW_of(c, l), c->gw_scratch, c->n_rows, y.F, y.HD, kPartRight, st, c->ld0);
     }
-    return launch_grad_w(gPL_rows, gPR_of(c, l), Xin_of(c, l), gW_of(c, l), c->gw_scratch + c->gw_off[(size_t)l], c->n_rows, y.F, y.HD, kPartBoth, st);
+    return launch_grad_w(gPL_rows, gPR_of(c, l), Xin_of(c, l), gW_of(c, l), c->gw_scratch + c->gw_off[(size_t)l], c->n_rows, y.F, y.HD, kPartBoth, st, ldX_of(c, l));
 }
 static int backward_grad_x(gat_ctx* c, int32_t l) {
     if (l == 0) return 0;                                             // E:1528
@@ -982,8 +997,8 @@ static int forward_exchange_pipelined(gat_ctx* c, int l) {
         const int64_t r0 = (int64_t)k * rpc, r1s = std::min<int64_t>(r0 + rpc, max_rows), r1 = std::min<int64_t>(r1s, c->n_rows);
         if (r0 >= max_rows) break;
         if (r1 > r0)
-            GAT_TRY(launch_project(Xin_of(c, l) + r0 * y.F, W_of(c, l), reinterpret_cast<float*>(own_rows + r0 * y.HD * st_bytes(c)),
-                                   y.PR + r0 * y.HD, r1 - r0, y.F, y.HD, kPartBoth, bf16(c), nullptr, 0, c->stream));
+            GAT_TRY(launch_project(Xin_of(c, l) + r0 * ldX_of(c, l), W_of(c, l), reinterpret_cast<float*>(own_rows + r0 * y.HD * st_bytes(c)),
+                                   y.PR + r0 * y.HD, r1 - r0, y.F, y.HD, kPartBoth, bf16(c), nullptr, 0, c->stream, ldX_of(c, l)));
         GAT_HIP(hipEventRecord(c->comm_events[k], c->stream));
         GAT_HIP(hipStreamWaitEvent(c->comm_stream, c->comm_events[k], 0));
         GAT_TRY(c->comm->all_gather_part(y.PL, pl_slice(c, y), r0 * rowf, (r1s - r0) * rowf, c->comm_stream));

@@ -751,7 +751,7 @@ template <bool VEC4, int WM, int BN = 128>
 __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gPL, const float* __restrict__ gPR,
                                                     const float* __restrict__ X, float* __restrict__ slabs,
                                                     int64_t n_rows, int32_t HD, int32_t F, int64_t kchunk,
-                                                    int32_t c_base, int32_t M) {
+                                                    int32_t c_base, int32_t M, int32_t ldx) {
     // BN = 64 when F <= 64 (hidden layers: F = H*D of the layer below): no MFMA spent on columns beyond F
     constexpr int KT = 32, BM = 64 * WM;
     constexpr int WN = 4 / WM, NY = BN / WN / 32;     // waves along f; 32-col MFMA tiles per wave
@@ -786,14 +786,14 @@ __global__ __launch_bounds__(256) void gradw_kernel(const float* __restrict__ gP
                 if constexpr (VEC4) {
                     if (c < BM && i0 + c < M) ra[p] = ci < HD ? *reinterpret_cast<const float4*>(gPL + node * HD + ci)
                                                     : *reinterpret_cast<const float4*>(gPR + node * HD + (ci - HD));
-                    if (c < BN && cj < F) rb[p] = *reinterpret_cast<const float4*>(X + node * F + cj);
+                    if (c < BN && cj < F) rb[p] = *reinterpret_cast<const float4*>(X + node * ldx + cj);
                 } else {
                     float t[4], u[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int cc = ci + q, jj = cj + q;
                         t[q] = (c < BM && (cc - c_base) < M) ? (cc < HD ? gPL[node * HD + cc] : gPR[node * HD + (cc - HD)]) : 0.f;
-                        u[q] = (c < BN && jj < F) ? X[node * F + jj] : 0.f;
+                        u[q] = (c < BN && jj < F) ? X[node * ldx + jj] : 0.f;
                     }
                     ra[p] = make_float4(t[0], t[1], t[2], t[3]);
                     rb[p] = make_float4(u[0], u[1], u[2], u[3]);
@@ -888,7 +888,7 @@ template <bool VEC4, int WM, int BN, int kDepth = 4>
 __global__ __launch_bounds__(256) void gradw_x3_kernel(const float* __restrict__ gPL, const float* __restrict__ gPR,
                                                        const float* __restrict__ X, float* __restrict__ slabs,
                                                        int64_t n_rows, int32_t HD, int32_t F, int64_t kchunk,
-                                                       int32_t c_base, int32_t M) {
+                                                       int32_t c_base, int32_t M, int32_t ldx /* floats between rows of X (>= F) */) {
     constexpr int KT = 16, BM = 64 * WM;
     constexpr int WN = 4 / WM, NY = BN / WN / 32;
     static_assert(NY >= 1, "tile shape");
@@ -943,11 +943,11 @@ __global__ __launch_bounds__(256) void gradw_x3_kernel(const float* __restrict__
             const int cj = j0 + c;
             if (node < ke && cj < F) {
                 if constexpr (VEC4) {
-                    t.b[p] = *reinterpret_cast<const float4*>(X + node * F + cj);
+                    t.b[p] = *reinterpret_cast<const float4*>(X + node * ldx + cj);
                 } else {
                     float v[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (cj + q < F) ? X[node * F + cj + q] : 0.f;
+                    for (int q = 0; q < 4; ++q) v[q] = (cj + q < F) ? X[node * ldx + cj + q] : 0.f;
                     t.b[p] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
@@ -1089,11 +1089,12 @@ int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD, int32_t pa
 }
 
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows, int32_t F,
-                   int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s) {
+                   int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s, int32_t ldx) {
     const int32_t j0 = part == kPartRight ? HD : 0;
-    ASrcRows as{X, F};
+    if (ldx < F) ldx = F;
+    ASrcRows as{X, ldx};
     BSrcProject bs{W, F, HD, j0};
-    const bool vec4 = (F % 4 == 0) && aligned16(X);
+    const bool vec4 = (ldx % 4 == 0) && aligned16(X);      // F itself, or a padded pitch with zeros behind column F (see launch_grad_w)
     const int32_t N = part == kPartBoth ? 2 * HD : HD;
     // split-K only when the caller's scratch holds this launch's slabs (the capacity is the caller's to state: a buffer
     // sized for another (rows, part) pair must not be overrun) — otherwise the streaming kernel, same results up to summation order
@@ -1169,8 +1170,9 @@ int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD) {
 }
 
 int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float* gradW, float* scratch,
-                  int64_t n_rows, int32_t F, int32_t HD, int32_t part, hipStream_t s) {
+                  int64_t n_rows, int32_t F, int32_t HD, int32_t part, hipStream_t s, int32_t ldx) {
     if (n_rows <= 0) return 0;
+    if (ldx < F) ldx = F;
     const int M = part == kPartBoth ? 2 * HD : HD;
     const int c_base = part == kPartRight ? HD : 0;
     if (part == kPartLeft) gPR = gPL_rows;           // never dereferenced; keeps the alignment test meaningful
@@ -1179,11 +1181,13 @@ int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float
     const int64_t ksplit = (n_rows + kchunk - 1) / kchunk;
     const int bm = grad_w_bm(M), bn = grad_w_bn(M, F);
     const dim3 grid((unsigned)((F + bn - 1) / bn), (unsigned)((M + bm - 1) / bm), (unsigned)ksplit);
-    const bool vec4 = (F % 4 == 0) && (HD % 4 == 0) && aligned16(X) && aligned16(gPL_rows) && aligned16(gPR);
+    // 16-byte loads need a row pitch of whole float4s: F itself, or the caller's padded pitch (zeros behind column F: the context
+    // pads an odd in_dim — Cora's 1,433 — once at gat_set_features)
+    const bool vec4 = (ldx % 4 == 0) && (HD % 4 == 0) && aligned16(X) && aligned16(gPL_rows) && aligned16(gPR);
 #define GAT_GRADW(V_, WM_, BN_)                                                                                             \
     do {                                                                                                                    \
-        if (grad_w_x3()) hipLaunchKernelGGL((gradw_x3_kernel<V_, WM_, BN_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M); \
-        else hipLaunchKernelGGL((gradw_kernel<V_, WM_, BN_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M); \
+        if (grad_w_x3()) hipLaunchKernelGGL((gradw_x3_kernel<V_, WM_, BN_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M, ldx); \
+        else hipLaunchKernelGGL((gradw_kernel<V_, WM_, BN_>), grid, dim3(256), 0, s, gPL_rows, gPR, X, scratch, n_rows, HD, F, kchunk, c_base, M, ldx); \
     } while (0)
     if (vec4) { if (bm == 128 && bn == 64) GAT_GRADW(true, 2, 64); else if (bm == 128) GAT_GRADW(true, 2, 128); else GAT_GRADW(true, 1, 128); }
     else { if (bm == 128 && bn == 64) GAT_GRADW(false, 2, 64); else if (bm == 128) GAT_GRADW(false, 2, 128); else GAT_GRADW(false, 1, 128); }

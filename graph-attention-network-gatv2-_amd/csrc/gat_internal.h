@@ -279,13 +279,15 @@ enum : int32_t { kPartBoth = 0, kPartLeft = 1, kPartRight = 2 };
 // needs one), or null; few rows with a long K (Cora / Pubmed shapes) take a split-K path through it.  A scratch smaller than
 // this launch needs (or null) selects the streaming kernel — never an overrun.
 int64_t project_scratch_floats(int64_t n_rows, int32_t F, int32_t HD, int32_t part);
+// ldx: floats between consecutive rows of X (0 = F).  A pitch that is a multiple of 4 with ZEROS behind column F lets the kernels use
+// 16-byte loads for an odd F (a float4 that starts below F may read up to three padding floats: they must be finite).
 int launch_project(const float* X, const float* W, float* PL_rows, float* PR, int64_t n_rows,
-                   int32_t F, int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s);
+                   int32_t F, int32_t HD, int32_t part, bool pl_bf16, float* scratch, int64_t scratch_floats, hipStream_t s, int32_t ldx = 0);
 // gradW[j][0:F] += sum_n gPL[n][j] X[n][:],  gradW[j][F:2F] += sum_n gPR[n][j] X[n][:]
 // scratch: at least grad_w_scratch_floats(n_rows, F, HD) floats.
 int64_t grad_w_scratch_floats(int64_t n_rows, int32_t F, int32_t HD);
 int launch_grad_w(const float* gPL_rows, const float* gPR, const float* X, float* gradW,
-                  float* scratch, int64_t n_rows, int32_t F, int32_t HD, int32_t part, hipStream_t s);
+                  float* scratch, int64_t n_rows, int32_t F, int32_t HD, int32_t part, hipStream_t s, int32_t ldx = 0);
 // gprev[n][f] = (sum_j gPL[n][j] W[j][f] + gPR[n][j] W[j][F+f]) * LReLU'(hpre_prev[n][f])
 // hpre_prev == nullptr: the plain sum is stored (the consumer applies LReLU', see EdgeBwdArgs::g_raw)
 int launch_grad_x(const float* gPL_rows, const float* gPR, const float* W, const float* hpre_prev,
