@@ -29,7 +29,7 @@ SNIPPET = """
         draws += 1
         heads, outdims = SHAPES[rng.integers(len(SHAPES))]
         n = int(rng.choice([1, 2, 3, 5, 17, 64, 130, 257]))
-        f = int(rng.choice([3, 8, 20, 33]))
+        f = int(rng.choice([1, 3, 5, 8, 20, 33, 130, 257]))     # odd widths: the padded feature pitch; > 128: the split-K projection
         c = int(rng.integers(2, 6))
         deg = rng.integers(0, 9, n)
         if n > 4 and rng.random() < 0.7:
