@@ -10,6 +10,11 @@
 //   pos[e]      = slot of CSR edge e in (src, e)-sorted order   (stable radix sort: fixed order
 //                 inside every source's list => bitwise reproducible sums)
 //   src_ptr[s]  = first slot of table row s, src_ptr[n_table] = E
+//   csc_src[j]  = table row of slot j (the sorted keys), csc_dst[j] = destination row of slot j
+// Two families of second-pass kernels: LIST kernels (a source's slot list per wave or lane group: gpl_pull_kernel, gpl_pull3_kernel,
+// gpl_sum_*; long lists chunked) for graphs with ~25 slots per list, and the SLOT-PARALLEL form (runs of consecutive slots per
+// lane group, segmented by csc_src: gpl_pull_runs_kernel, gpl_sum_runs_kernel) where lists are short — destination-range shards
+// and sparse graphs (round 4).  run_pull / launch_gpl_sum hold the selection rules and the measurements behind them.
 #include "gat_internal.h"
 
 #include <hipcub/hipcub.hpp>
