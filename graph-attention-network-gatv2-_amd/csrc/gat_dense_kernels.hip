@@ -572,7 +572,9 @@ static int head_tile(int32_t C, int32_t DL, int32_t extra_per_row, int32_t* NB, 
     return 0;
 }
 int head_blocks(int64_t n_rows) {
-    const int64_t b = (n_rows + 255) / 256;
+    // nodes per block: 128 = one tile of the fused head kernel per block (GAT_HEAD_NODES=256: two tiles in sequence per block, as before)
+    static const int per = [] { const char* e = choice_env("GAT_HEAD_NODES"); const int v = e ? atoi(e) : 0; return v == 256 ? 256 : 128; }();
+    const int64_t b = (n_rows + per - 1) / per;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 int launch_head_forward(const HeadArgs& a, hipStream_t s) {
