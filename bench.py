@@ -284,8 +284,12 @@ def main():
                     ctx.comm_option(A.COMM_HALO, args.halo)
                 runner = ctx
             else:
-                runner = S.ShardedGat(ctx, plan, S.TorchComm(), heads, outdims,
-                                      alloc=lambda k: torch.empty(k, dtype=torch.float32, device=dev))
+                tcomm = S.TorchComm()
+                if args.halo:                       # torch.distributed twin of GAT_COMM_HALO (value 2: by the referenced fraction)
+                    frac = tcomm.halo_setup(plan, ci_l)
+                runner = S.ShardedGat(ctx, plan, tcomm, heads, outdims,
+                                      alloc=lambda k: torch.empty(k, dtype=torch.float32, device=dev),
+                                      halo=bool(args.halo == 1 or (args.halo == 2 and frac < 0.5)))
         del row_ptr, dsd
         torch.cuda.empty_cache()
         ctx.params_init(42)

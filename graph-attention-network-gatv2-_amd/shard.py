@@ -148,6 +148,72 @@ class TorchComm:
         self.dist.all_reduce(host, group=self.group)
         t[self.rank].copy_(host.view(self.world, -1)[self.rank])
 
+    # ---- halo form of the two table exchanges (the library's own is csrc/gat_halo.hip: gat_comm_option GAT_COMM_HALO) ----
+    def halo_setup(self, plan: "ShardPlan", col_idx_local):
+        """Collective, once per graph.  col_idx_local: this shard's sources as TABLE row ids (local_csr).  Per peer q the sorted
+        rows of q's slice this shard references (need[q]); the lists are all-gathered so that every rank also knows what each peer
+        wants from it (send[p] = need_p[rank], as local row ids)."""
+        import torch
+        ref = np.unique(np.asarray(col_idx_local, np.int64))
+        owner = ref // plan.max_rows
+        need = [ref[owner == q] if q != self.rank else ref[:0] for q in range(self.world)]
+        lists = [None] * self.world
+        self.dist.all_gather_object(lists, [(n % plan.max_rows).astype(np.int64) for n in need], group=self.group)
+        self._halo = dict(
+            max_rows=plan.max_rows,
+            need=[torch.from_numpy(n.astype(np.int64)) for n in need],                      # table rows, per owner
+            send=[torch.from_numpy(np.asarray(lists[p][self.rank], np.int64)) for p in range(self.world)])   # own local rows, per requester
+        rows = sum(len(lists[p][q]) for p in range(self.world) for q in range(self.world))
+        self.halo_fraction = rows / max(1, self.world * (self.world - 1) * plan.max_rows)
+        return self.halo_fraction
+
+    def _pairwise(self, send_bufs, recv_bufs):
+        """One send / receive per peer (host tensors on a non-RCCL backend)."""
+        ops = []
+        for q in range(self.world):
+            if q == self.rank:
+                continue
+            if send_bufs[q].numel():
+                ops.append(self.dist.P2POp(self.dist.isend, send_bufs[q], q, group=self.group))
+            if recv_bufs[q].numel():
+                ops.append(self.dist.P2POp(self.dist.irecv, recv_bufs[q], q, group=self.group))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def halo_gather_rows(self, table, row_floats: int):
+        """Forward: only the rows each peer's edges reference travel; they land in the same table rows as a full all-gather's."""
+        h = self._halo
+        t = table.view(self.world * h["max_rows"], row_floats)
+        own = t[self.rank * h["max_rows"]:(self.rank + 1) * h["max_rows"]]
+        dev = table.device
+        stage = (lambda x: x) if self.native else (lambda x: x.cpu())
+        send = [stage(own.index_select(0, h["send"][q].to(dev))).contiguous() for q in range(self.world)]
+        recv = [send[0].new_empty((len(h["need"][q]), row_floats)) for q in range(self.world)]
+        self._pairwise(send, recv)
+        for q in range(self.world):
+            if q != self.rank and len(h["need"][q]):
+                t.index_copy_(0, h["need"][q].to(dev), recv[q].to(dev))
+
+    def halo_reduce_rows(self, table, row_floats: int):
+        """Backward: the mirror — the partial sums of the rows this shard references go back to their owners, which add the arrivals
+        in ascending rank order with the own partial at its rank's position (the order of a rank-ordered reduce-scatter)."""
+        h = self._halo
+        t = table.view(self.world * h["max_rows"], row_floats)
+        own = t[self.rank * h["max_rows"]:(self.rank + 1) * h["max_rows"]]
+        dev = table.device
+        stage = (lambda x: x) if self.native else (lambda x: x.cpu())
+        send = [stage(t.index_select(0, h["need"][q].to(dev))).contiguous() for q in range(self.world)]
+        recv = [send[0].new_empty((len(h["send"][q]), row_floats)) for q in range(self.world)]
+        self._pairwise(send, recv)
+        acc = own.new_zeros(own.shape)
+        for q in range(self.world):
+            if q == self.rank:
+                acc += own
+            elif len(h["send"][q]):
+                acc.index_add_(0, h["send"][q].to(dev), recv[q].to(dev))
+        own.copy_(acc)
+
     def all_reduce_(self, tensor):
         if self.native:
             self.dist.all_reduce(tensor, group=self.group)
@@ -168,8 +234,9 @@ class ShardedGat:
     ``tables`` maps (which, layer) -> flat torch tensor bound to the context."""
 
     def __init__(self, ctx, plan: ShardPlan, comm, heads: Sequence[int], outdims: Sequence[int],
-                 alloc: Callable[[int], "object"]):
+                 alloc: Callable[[int], "object"], halo: bool = False):
         self.ctx, self.plan, self.comm = ctx, plan, comm
+        self.halo = bool(halo)                         # comm.halo_setup(plan, col_idx_local) must have run (collective)
         self.hd = [int(h) * int(d) for h, d in zip(heads, outdims)]
         self.L = len(self.hd)
         self.pl = []
@@ -192,7 +259,11 @@ class ShardedGat:
         for l in range(self.L):
             self.ctx.layer_project(l)
             if self.exchange[l]:
-                self.comm.all_gather_rows(self.pl[l], self.hd[l])
+                sb = getattr(self.ctx, "storage_bytes", 4)
+                if self.halo:
+                    self.comm.halo_gather_rows(self.pl[l], self.hd[l] * sb // 4)
+                else:
+                    self.comm.all_gather_rows(self.pl[l], self.hd[l])
             self.ctx.layer_forward_edges(l)
 
     def _backward_phases(self):
@@ -200,7 +271,10 @@ class ShardedGat:
         for l in range(self.L - 1, -1, -1):
             self.ctx.layer_backward_edges(l)
             if self.exchange[l]:
-                self.comm.reduce_scatter_rows(self.gpl[: self.plan.n_table * self.hd[l]], self.hd[l])
+                if self.halo:
+                    self.comm.halo_reduce_rows(self.gpl[: self.plan.n_table * self.hd[l]], self.hd[l])
+                else:
+                    self.comm.reduce_scatter_rows(self.gpl[: self.plan.n_table * self.hd[l]], self.hd[l])
             self.ctx.layer_backward_dense(l)
 
     def forward(self):

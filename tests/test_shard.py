@@ -127,7 +127,7 @@ def _want(pkg, orc, P, W, a, Wo, ref, use_gpu):
         return np.concatenate([ctx.grads_get(g) for g in range(3)]), 1e-5
 
 
-def _worker(rank, world, port, outdir, use_gpu, replicate):
+def _worker(rank, world, port, outdir, use_gpu, replicate, halo=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -164,7 +164,11 @@ def _worker(rank, world, port, outdir, use_gpu, replicate):
         for g, arr in enumerate((W, a, Wo)):
             ctx.params_set(g, arr)
         ctx.zero_grad()
-        run = S.ShardedGat(ctx, plan, S.TorchComm(), P["heads"], P["outdims"], alloc=alloc)
+        comm = S.TorchComm()
+        if halo:                                   # only the rows each shard's edges reference travel (the torch.distributed twin of
+            frac = comm.halo_setup(plan, ci_l)     # the library's GAT_COMM_HALO); collective
+            assert 0 < frac <= 1
+        run = S.ShardedGat(ctx, plan, comm, P["heads"], P["outdims"], alloc=alloc, halo=halo)
         assert run.exchange == [not replicate] + [True] * (len(P["heads"]) - 1)
         loss, correct = run.forward()
         run.backward()
@@ -179,7 +183,7 @@ def _worker(rank, world, port, outdir, use_gpu, replicate):
         dist.destroy_process_group()
 
 
-def _run_world(world, use_gpu, pkg, orc, replicate=False):
+def _run_world(world, use_gpu, pkg, orc, replicate=False, halo=False):
     import torch.multiprocessing as mp
     P = _problem()
     cfg = orc.Config(P["heads"], P["outdims"], P["f"], P["c"])
@@ -188,7 +192,7 @@ def _run_world(world, use_gpu, pkg, orc, replicate=False):
     want, tol = _want(pkg, orc, P, W, a, Wo, ref, use_gpu)
     port = 29500 + (os.getpid() % 2000) + world
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, d, use_gpu, replicate), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, d, use_gpu, replicate, halo), nprocs=world, join=True)
         outs = [np.load(os.path.join(d, f"r{r}.npz")) for r in range(world)]
     for o in outs:       # every rank holds the global loss and the all-reduced gradients
         assert abs(float(o["loss"]) - ref.loss_sum_f64) < 1e-4 * P["n"]
@@ -200,6 +204,18 @@ def _run_world(world, use_gpu, pkg, orc, replicate=False):
 @pytest.mark.parametrize("world,replicate", [(2, False), (3, False), (2, True), (3, True)])
 def test_sharded_step_gloo_cpu(pkg, orc, world, replicate):
     _run_world(world, False, pkg, orc, replicate)
+
+
+@pytest.mark.parametrize("world,replicate", [(2, False), (3, False), (4, False), (3, True)])
+def test_sharded_step_halo_gloo_cpu(pkg, orc, world, replicate):
+    """The halo form of the two table exchanges over torch.distributed (gloo, CPU, world 2 / 3 / 4): per peer only the rows a shard's
+    edges reference travel, forward and backward; same loss, #correct and gradients as the single-process result."""
+    _run_world(world, False, pkg, orc, replicate, halo=True)
+
+
+@pytest.mark.gpu
+def test_sharded_step_halo_two_ranks_one_gpu(pkg, orc):
+    _run_world(2, True, pkg, orc, False, halo=True)
 
 
 @pytest.mark.gpu
