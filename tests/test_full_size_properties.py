@@ -93,3 +93,69 @@ def test_arxiv_shape_three_layers_phase_api(pkg):
             assert np.array_equal(c1.grads_get(g), c2.grads_get(g))
     finally:
         c1.close(); c2.close()
+
+
+def test_shard_shape_slot_parallel_pull_equals_list_pull_and_is_reproducible(tmp_path):
+    """The P = 8 destination-range shard of the Products graph (7.7 M edges against the 2.47 M-row table: where the slot-parallel
+    source-major pass is the default) at FULL size, driven through the phase API with the other ranks' table slices filled with
+    fixed random rows: the step run twice is bitwise reproducible, and its gPL TABLES (every row, both layers — the last one
+    through the node-record variant) and parameter gradients agree with the list-per-group pull kernels (GAT_PULL_RUNS=0) up to
+    fp32 summation order."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path.insert(0, {root!r})
+        import __graft_entry__ as entry
+        pkg = entry.load_package(); A = pkg.abi; S = pkg.shard
+        dev = torch.device("cuda", 0)
+        dsd = pkg.synth.make_dataset_device("products", dev)
+        row_ptr, col_idx = dsd["row_ptr"], dsd["d_col_idx"].cpu().numpy()
+        x_all, lab_all = dsd["d_x"].cpu().numpy(), dsd["d_labels"].cpu().numpy()
+        del dsd; torch.cuda.empty_cache()
+        plan = S.make_plan(row_ptr, 8, 3)
+        rp_l, ci_l = S.local_csr(plan, row_ptr, col_idx)
+        lo, hi = plan.row0, plan.row0 + plan.n_rows
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            ctx = pkg.GatContext([8, 8], [8, 8], 100, 47, device=0, stream=stream.cuda_stream)
+            ctx.set_graph(rp_l, ci_l, n_table=plan.n_table, table_row0=plan.table_row0)
+            ctx.set_features(x_all[lo:hi]); ctx.set_labels(lab_all[lo:hi])
+            ctx.params_init(42)
+            g = torch.Generator(device=dev); g.manual_seed(1)
+            pl = [0.1 * torch.randn(plan.n_table * 64, generator=g, device=dev) for _ in range(2)]      # the other ranks' rows
+            gpl = torch.zeros(plan.n_table * 64, device=dev)
+            for l in range(2):
+                ctx.bind_table(A.TABLE_PL, l, pl[l].data_ptr(), pl[l].numel() * 4)
+            ctx.bind_table(A.TABLE_GPL, 0, gpl.data_ptr(), gpl.numel() * 4)
+            outs = []
+            for rep in range(2):
+                ctx.zero_grad()
+                for l in range(2):
+                    ctx.layer_project(l); ctx.layer_forward_edges(l)
+                ctx.head_forward(want_loss=False); ctx.head_backward()
+                tabs = []
+                for l in (1, 0):
+                    ctx.layer_backward_edges(l)
+                    ctx.sync()
+                    tabs.append(gpl.clone())
+                    ctx.layer_backward_dense(l)
+                ctx.sync()
+                outs.append((np.concatenate([ctx.grads_get(k).ravel() for k in range(3)]), tabs))
+            assert np.array_equal(outs[0][0], outs[1][0])
+            assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[0][1], outs[1][1]))
+            np.savez(sys.argv[1], grads=outs[0][0], gpl1=outs[0][1][0].cpu().numpy(), gpl0=outs[0][1][1].cpu().numpy())
+            ctx.close()
+        print("OK")
+    """)
+    res = []
+    for tag, env in (("runs", {}), ("lists", {"GAT_PULL_RUNS": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        out = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+        res.append(np.load(f))
+    for key, tol in (("grads", 2e-5), ("gpl1", 1e-5), ("gpl0", 1e-5)):
+        a_, b_ = res[0][key], res[1][key]
+        scale = np.abs(b_).max()
+        assert np.isfinite(a_).all() and scale > 0
+        assert np.abs(a_ - b_).max() <= tol * scale, (key, np.abs(a_ - b_).max() / scale)
