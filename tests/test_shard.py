@@ -412,6 +412,25 @@ def test_library_transport_rccl_world1(pkg, orc):
     parity.check_rel("rccl world 1", grads, want, tol)
 
 
+@pytest.mark.gpu
+def test_halo_option_error_paths(pkg):
+    """GAT_COMM_HALO needs a transport, takes 0 / 1 / 2, and reports nothing before it was set; gat_switches refuses a buffer that is too small."""
+    import ctypes as C
+    P = _problem()
+    ctx = pkg.GatContext(P["heads"], P["outdims"], P["f"], P["c"], device=0)
+    ctx.set_graph(P["rp"], P["ci"]); ctx.set_features(P["x"]); ctx.set_labels(P["lab"])
+    assert ctx.comm_halo_info() == (False, 0, 0, 1.0)
+    with pytest.raises(pkg.abi.GatError, match="transport"):
+        ctx.comm_option(pkg.abi.COMM_HALO, 1)
+    with pytest.raises(pkg.abi.GatError, match="0 .off., 1 .on. or 2"):
+        ctx.comm_option(pkg.abi.COMM_HALO, 7)
+    ctx.comm_option(pkg.abi.COMM_HALO, 0)            # off is always legal
+    ctx.close()
+    lib = pkg.abi.load_library()
+    assert lib.gat_switches(C.create_string_buffer(1), 0) != 0 and lib.gat_switches(None, 64) != 0
+    assert isinstance(pkg.abi.switches(), str)
+
+
 def _dead_peer_worker(rank, world, outdir, shm):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["GAT_COMM_TIMEOUT_S"] = "3"
